@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE itself (imported from /root/reference) on the
+seeded recipes of tests/golden_cases.py.  Run in the build container only:
+
+    python oracle/make_golden.py            # writes tests/golden/<case>.npz
+
+The reference never travels: only its outputs are stored (inputs are rebuilt from the recipe).
+Test infrastructure — see oracle/dygformer_oracle.py header.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("DYGLIB_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+from models.DyGFormer import DyGFormer as RefDyGFormer          # noqa: E402  (reference)
+from models.modules import MergeLayer as RefMergeLayer          # noqa: E402  (reference)
+from utils.DataLoader import Data as RefData                    # noqa: E402  (reference)
+from utils.utils import get_neighbor_sampler as ref_get_neighbor_sampler  # noqa: E402  (reference)
+
+from tests import golden_cases as gc                             # noqa: E402
+
+
+def run_case(name: str) -> dict:
+    c = gc.build_case(name)
+    d, cfg = c["data"], c["cfg"]
+    ref_data = RefData(d.src_node_ids, d.dst_node_ids, d.node_interact_times, d.edge_ids, d.labels)
+    sampler = ref_get_neighbor_sampler(ref_data, sample_neighbor_strategy="recent", seed=1)
+    model = RefDyGFormer(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"],
+                         channel_embedding_dim=cfg["channel_embedding_dim"], patch_size=cfg["patch_size"],
+                         num_layers=cfg["num_layers"], num_heads=cfg["num_heads"], dropout=0.1,
+                         max_input_sequence_length=cfg["max_input_sequence_length"], device="cpu")
+    missing = model.load_state_dict({k: torch.from_numpy(v) for k, v in c["params"].items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    merge = RefMergeLayer(172, 172, 172, 1)
+    merge.load_state_dict({k: torch.from_numpy(v) for k, v in c["mparams"].items()}, strict=True)
+    model.eval(), merge.eval()
+
+    out = {}
+    src, dst, neg, t = c["src"], c["dst"], c["neg_dst"], c["times"]
+
+    # --- sampler: get_historical_neighbors('recent') on src and dst queries
+    q_nodes = np.concatenate([src, dst])
+    q_times = np.concatenate([t, t])
+    for k in gc.SAMPLER_KS:
+        n, e, ts = sampler.get_historical_neighbors(q_nodes, q_times, num_neighbors=k)
+        out[f"recent{k}_nbr"], out[f"recent{k}_eid"], out[f"recent{k}_ts"] = n, e, ts
+    # TGAT-style second hop: float32-rounded query times (models/TGAT.py:107-110)
+    n, e, ts = sampler.get_historical_neighbors(q_nodes, q_times, num_neighbors=10)
+    n2, e2, ts2 = sampler.get_historical_neighbors(n.flatten(), ts.flatten(), num_neighbors=10)
+    out["hop2_nbr"], out["hop2_eid"], out["hop2_ts"] = n2, e2, ts2
+
+    # --- first-hop counts, padded windows and co-occurrence counts for (src, dst)
+    sides = {}
+    for tag, ids in (("src", src), ("dst", dst)):
+        a, b, cc = sampler.get_all_first_hop_neighbors(ids, t)
+        out[f"{tag}_hist_len"] = np.array([len(x) for x in a], dtype=np.int64)
+        pid, pe, pt = model.pad_sequences(ids, t, a, b, cc, patch_size=cfg["patch_size"],
+                                          max_input_sequence_length=cfg["max_input_sequence_length"])
+        sides[tag] = pid
+        out[f"{tag}_pad_ids"], out[f"{tag}_pad_eids"], out[f"{tag}_pad_times"] = pid, pe, pt
+    cs, cd = model.neighbor_co_occurrence_encoder.count_nodes_appearances(sides["src"], sides["dst"])
+    out["src_counts"], out["dst_counts"] = cs.numpy(), cd.numpy()
+
+    # --- full forward with taps
+    taps = {"layers": []}
+    h0 = model.transformers[0].register_forward_pre_hook(lambda m, inp: taps.__setitem__("enc_in", inp[0].detach().clone()))
+    hs = [tr.register_forward_hook(lambda m, inp, o: taps["layers"].append(o.detach().clone())) for tr in model.transformers]
+    with torch.no_grad():
+        se, de = model.compute_src_dst_node_temporal_embeddings(src, dst, t)
+    h0.remove()
+    [h.remove() for h in hs]
+    R = gc.TAP_ROWS
+    out["encoder_input_rows"] = taps["enc_in"][:R].numpy()
+    for l, x in enumerate(taps["layers"]):
+        out[f"layer{l}_rows"] = x[:R].numpy()
+    out["src_emb"], out["dst_emb"] = se.numpy(), de.numpy()
+    with torch.no_grad():
+        nse, nde = model.compute_src_dst_node_temporal_embeddings(src, neg, t)
+        out["neg_src_emb"], out["neg_dst_emb"] = nse.numpy(), nde.numpy()
+        out["pos_prob"] = merge(se, de).squeeze(-1).sigmoid().numpy()
+        out["neg_prob"] = merge(nse, nde).squeeze(-1).sigmoid().numpy()
+    out["torch_version"] = np.array(torch.__version__)
+    return out
+
+
+def main():
+    os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
+    torch.set_num_threads(8)
+    names = sys.argv[1:] or list(gc.CASES)
+    for name in names:
+        out = run_case(name)
+        path = os.path.join(gc.GOLDEN_DIR, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB  "
+              f"S_src={out['src_pad_ids'].shape[1]} S_dst={out['dst_pad_ids'].shape[1]} B={len(out['src_emb'])}")
+
+
+if __name__ == "__main__":
+    main()
