@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: positive edges / second through the DyGFormer link-prediction forward step
+(BASELINE.json metric; body of reference evaluate_models_utils.py:126-141) on the Wikipedia-shaped
+synthetic workload of SURVEY.md §8(d): L=64, P=2, batch 200, 2 layers, 2 heads, C=50.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One step = one 200-edge batch: hot-path call on (src,dst,t) + hot-path call on (src,neg_dst,t) +
+sigmoid(MergeLayer) on both + the per-step metric (AUC numerator) reduced over RCCL when N>1.
+Inputs (graph, feature tables, weights, every batch's id/time arrays) are resident in HBM before the
+timed region.  N>1: one process per GPU, graph/tables/weights replicated, whole batches dealt
+round-robin (rank r takes batches r, r+N, ...: weak scaling, K steps per rank), no data-path
+collective.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from dyglib_amd import synthetic as syn  # noqa: E402
+
+# algorithmic work of one (src,dst,t) pair at S_src = S_dst = 64 (every batch of this
+# workload), multiply-add = 2 flops; and the fp32 MFMA peak of MI355X_MICROARCH.md.
+FLOP_PER_PAIR = 137.2e6
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+WORKLOADS = {
+    # name: users, items, edges, L, P, batch
+    "wikipedia": dict(users=8227, items=1000, edges=157474, L=64, P=2, batch=200),
+    "tiny": dict(users=300, items=50, edges=12000, L=64, P=2, batch=200),        # CI / smoke sizes
+}
+
+
+def flops_per_pair(S_s: int, S_d: int, P: int, Fn=172, Ft=100, C=50, layers=2) -> float:
+    """SURVEY.md §8(d) formula."""
+    S, D = S_s + S_d, 4 * C
+    T = S // P
+    return (2 * Ft * S + S * 2 * (2 * C + 2 * C * C) + T * 2 * C * P * (2 * Fn + Ft + C)
+            + layers * (T * (2 * D * 3 * D + 2 * D * D + 4 * D * 4 * D) + 4 * T * T * D) + 2 * 2 * D * Fn)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="wikipedia", choices=list(WORKLOADS))
+    ap.add_argument("--impl", type=int, default=0, help="0 auto, 1 generic kernels, 2 fused kernel")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the independent hot-path calls are issued on")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the CPU-baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for N>1 launch with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from dyglib_amd import DyGFormer, MergeLayer, get_neighbor_sampler
+    wl = WORKLOADS[args.workload]
+    B, L, P = wl["batch"], wl["L"], wl["P"]
+    data, node_feat, edge_feat = syn.make_bipartite_graph(wl["users"], wl["items"], wl["edges"], seed=0)
+    params = syn.make_dygformer_params(0, patch_size=P)
+    mparams = syn.make_merge_layer_params(1000)
+    sampler = get_neighbor_sampler(data, "recent", seed=1, device=dev)              # full graph, as in evaluation
+    model = DyGFormer(node_feat, edge_feat, sampler, time_feat_dim=100, channel_embedding_dim=50, patch_size=P,
+                      num_layers=2, num_heads=2, dropout=0.1, max_input_sequence_length=L, device=dev)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    merge = MergeLayer(172, 172, 172, 1)
+    merge.load_state_dict({k: torch.from_numpy(v) for k, v in mparams.items()})
+    model, merge = model.to(dev).eval(), merge.to(dev).eval()
+    model.impl = args.impl
+
+    # evaluation span = last 30 % of the interactions (val + test), full batches only
+    E = data.num_interactions
+    first = int(E * 0.70)
+    n_batches = (E - first) // B
+    neg_rs = np.random.RandomState(2)
+    uniq_dst = np.unique(data.dst_node_ids)
+    batches = []
+    for i in range(n_batches):
+        sl = slice(first + i * B, first + (i + 1) * B)
+        neg = syn.random_negative_dst(neg_rs, uniq_dst, B)
+        batches.append((data.src_node_ids[sl], data.dst_node_ids[sl], neg, data.node_interact_times[sl]))
+    dev_batches = [tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in b) for b in batches]
+    streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))] if args.streams > 1 else [torch.cuda.current_stream(dev)]
+    # per-stream accumulators [sum AUC, sum mean-prob gap, steps] (no cross-stream read-modify-write)
+    metric_accs = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in streams]
+
+    def step(i: int, ev=None):
+        src, dst, neg, t = dev_batches[(i * world + rank) % n_batches]
+        st = streams[i % len(streams)]
+        with torch.cuda.stream(st), torch.no_grad():
+            if ev is not None:
+                ev[0].record(st)
+            s, d = model.compute_src_dst_node_temporal_embeddings(src, dst, t)
+            ns, nd = model.compute_src_dst_node_temporal_embeddings(src, neg, t)
+            if ev is not None:
+                ev[1].record(st)
+            pos = merge.link_probabilities(s, d)
+            negp = merge.link_probabilities(ns, nd)
+            # per-step ranking metric on device (AUC = P(pos > neg) over the 200x200 pairs), reduced over RCCL
+            auc = ((pos[:, None] > negp[None, :]).double().mean() + 0.5 * (pos[:, None] == negp[None, :]).double().mean())
+            m = torch.stack([auc, (pos.mean() - negp.mean()).double(), torch.ones((), dtype=torch.float64, device=dev)])
+            if dist is not None:
+                dist.all_reduce(m)
+            metric_accs[i % len(streams)].add_(m)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    [a.zero_() for a in metric_accs]
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, events[i])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    total_edges = args.steps * B * world
+    value = total_edges / elapsed
+    # hot-path kernel time per call from the HIP events recorded on the launch stream inside the timed region
+    call_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) / 2.0
+    S = 64 if L == 64 else None
+    fpp = flops_per_pair(L, L, P)
+    achieved_tflops = fpp * B / (call_ms * 1e-3) / 1e12
+    acc = sum(a.cpu().numpy() for a in metric_accs)
+
+    out = {
+        "metric": "edges/sec (link-prediction fwd) DyGFormer Wikipedia",
+        "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"DyGFormer link-prediction forward, synthetic {args.workload}-shaped graph "
+                               f"({wl['users']}+{wl['items']} nodes, {wl['edges']} edges), L={L}, P={P}, batch={B}, "
+                               f"2 layers, 2 heads, C=50; pos+neg calls + MergeLayer+sigmoid per step",
+                   "batch": B, "max_input_sequence_length": L, "patch_size": P,
+                   "parallelism": f"{world} x edge-batch shard, graph+weights replicated, metric all-reduce over RCCL",
+                   "impl": {0: "auto", 1: "generic", 2: "fused"}[args.impl], "streams": len(streams)},
+        "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                     "kernel": "DyGFormer hot-path call (window search + fused forward)",
+                     "flop_per_launch": fpp * B, "ms_per_launch": round(call_ms, 4)},
+        "mean_auc": round(float(acc[0] / max(acc[2], 1)), 4),
+    }
+
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline(params, mparams, node_feat, edge_feat, data, batches, L, P, args.cpu_seconds)
+        out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(params, mparams, node_feat, edge_feat, data, batches, L, P, budget_s):
+    """The CPU oracle (restatement of the reference path, kind 'port') timed on this host on a bounded
+    sample of the SAME workload: as many of the same 200-edge steps as fit in ~budget_s seconds."""
+    from oracle import dygformer_oracle as orc
+    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    nf, ef = torch.from_numpy(node_feat), torch.from_numpy(edge_feat)
+    tp = {k: torch.from_numpy(v) for k, v in params.items()}
+    mp = {k: torch.from_numpy(v) for k, v in mparams.items()}
+    cores = torch.get_num_threads()
+    src, dst, neg, t = batches[0]
+    orc.link_prediction_step(tp, mp, nf, ef, adj, src, dst, neg, t, P, L)        # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        src, dst, neg, t = batches[(n + 1) % len(batches)]
+        orc.link_prediction_step(tp, mp, nf, ef, adj, src, dst, neg, t, P, L)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    return {"value": round(n * len(src) / el, 1), "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"{n} of the same 200-edge steps ({el:.1f} s) after 1 warm-up step; oracle/dygformer_oracle.py "
+                      f"(numpy sampling + PyTorch-CPU fp32 dense ops, torch threads={cores})"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,81 @@
+"""In-tree build of libdygnn_hip.so with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m dyglib_amd._build [--force]
+
+The library is built next to its sources (dyglib_amd/csrc/libdygnn_hip.so): it is git-ignored but
+travels with the repository snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from typing import List
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+INCLUDE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+LIB_NAME = "libdygnn_hip.so"
+LIB_PATH = os.path.join(CSRC, LIB_NAME)
+SOURCES = ["csr_host.cpp", "sampler.hip", "cooccurrence.hip", "dygformer_generic.hip", "dygformer_fused.hip",
+           "dygformer_api.hip"]
+ARCH = "gfx950"
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+            "-ffp-contract=off"]   # contractions are written explicitly (fmaf) where the oracle has them
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for root in (CSRC, INCLUDE):
+        for fn in sorted(os.listdir(root)):
+            if fn.endswith((".hip", ".cpp", ".h")):
+                with open(os.path.join(root, fn), "rb") as f:
+                    h.update(fn.encode()), h.update(f.read())
+    h.update(" ".join(CXXFLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src: str, obj_dir: str) -> str:
+    obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+    cmd = [_hipcc(), *CXXFLAGS, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+    if src.endswith(".cpp"):
+        cmd.insert(1, "-x"), cmd.insert(2, "hip")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    stamp = os.path.join(CSRC, "build", "digest.txt")
+    digest = _digest()
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return LIB_PATH
+    obj_dir = os.path.join(CSRC, "build")
+    os.makedirs(obj_dir, exist_ok=True)
+    with cf.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+        objs: List[str] = list(ex.map(lambda s: _compile(s, obj_dir), SOURCES))
+    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB_PATH]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    with open(stamp, "w") as f:
+        f.write(digest)
+    if verbose:
+        print(f"built {LIB_PATH}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

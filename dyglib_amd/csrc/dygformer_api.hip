@@ -1,0 +1,140 @@
+// C-ABI entry points for the DyGFormer forward path + the fused link-predictor head.
+#include "dygformer_layout.h"
+
+namespace dygnn {
+// dygformer_generic.hip
+int pack_generic(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, float* packed, hipStream_t);
+int forward_generic(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, const float* packed, const dygnn_csr*,
+                    const float* node_feat, const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times,
+                    int64_t B, float* out_src, float* out_dst, char* ws, const WorkspaceLayout&, const dygnn_dygformer_taps*,
+                    hipStream_t);
+// dygformer_fused.hip
+bool fused_supported(const Dims&);
+int pack_fused(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, float* packed, hipStream_t);
+int forward_fused(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, const float* packed, const dygnn_csr*,
+                  const float* node_feat, const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times,
+                  int64_t B, float* out_src, float* out_dst, char* ws, const WorkspaceLayout&, const dygnn_dygformer_taps*,
+                  hipStream_t);
+
+static int check_weights(const Dims& d, const dygnn_dygformer_weights* w) {
+    DYGNN_REQUIRE(w != nullptr, "weights is NULL");
+    const void* p[] = {w->time_w, w->time_b, w->cooc_w0, w->cooc_b0, w->cooc_w1, w->cooc_b1, w->proj_node_w, w->proj_node_b,
+                       w->proj_edge_w, w->proj_edge_b, w->proj_time_w, w->proj_time_b, w->proj_cooc_w, w->proj_cooc_b,
+                       w->output_w, w->output_b};
+    for (const void* q : p) DYGNN_REQUIRE(q != nullptr, "weights: null parameter pointer");
+    for (int l = 0; l < d.NL; ++l) {
+        const dygnn_encoder_layer_weights& L = w->layers[l];
+        const void* r[] = {L.in_proj_weight, L.in_proj_bias, L.out_proj_weight, L.out_proj_bias, L.ffn0_weight, L.ffn0_bias,
+                           L.ffn1_weight, L.ffn1_bias, L.norm0_weight, L.norm0_bias, L.norm1_weight, L.norm1_bias};
+        for (const void* q : r) DYGNN_REQUIRE(q != nullptr, "weights: null parameter pointer in layer %d", l);
+    }
+    return DYGNN_OK;
+}
+
+// sigmoid(fc2(relu(fc1(cat(a,b)))))   models/modules.py:57-68 + evaluate_models_utils.py:140-141
+__global__ __launch_bounds__(256) void k_merge_sigmoid(const float* __restrict__ a, const float* __restrict__ b, int dim, int hidden,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* x = reinterpret_cast<float*>(smem);          // [2*dim]
+    float* red = x + 2 * dim;                           // [4]
+    const int64_t r = blockIdx.x;
+    for (int i = threadIdx.x; i < 2 * dim; i += blockDim.x) x[i] = i < dim ? a[r * dim + i] : b[r * dim + (i - dim)];
+    __syncthreads();
+    float part = 0.f;
+    for (int j = threadIdx.x; j < hidden; j += blockDim.x) {
+        float acc = 0.f;
+        const float* wr = w1 + (size_t)j * 2 * dim;
+        for (int k = 0; k < 2 * dim; ++k) acc = fmaf(x[k], wr[k], acc);
+        acc = fmaxf(acc + b1[j], 0.f);
+        part = fmaf(acc, w2[j], part);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float z = b2[0];
+        for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) z += red[wv];
+        out[r] = 1.0f / (1.0f + expf(-z));
+    }
+}
+
+}  // namespace dygnn
+
+using namespace dygnn;
+
+extern "C" size_t dygnn_dygformer_packed_bytes(const dygnn_dygformer_config* cfg) {
+    if (check_config(cfg) != DYGNN_OK) return 0;
+    const Dims d = make_dims(*cfg);
+    return make_packed_layout(d).total * sizeof(float);
+}
+
+extern "C" size_t dygnn_dygformer_workspace_bytes(const dygnn_dygformer_config* cfg, int64_t batch) {
+    if (check_config(cfg) != DYGNN_OK || batch < 0) return 0;
+    const Dims d = make_dims(*cfg);
+    return make_workspace_layout(d, batch).total;
+}
+
+extern "C" int dygnn_dygformer_pack(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, void* packed,
+                                    size_t packed_bytes, dygnn_stream_t stream) {
+    if (int rc = check_config(cfg)) return rc;
+    const Dims d = make_dims(*cfg);
+    if (int rc = check_weights(d, w)) return rc;
+    const PackedLayout pl = make_packed_layout(d);
+    DYGNN_REQUIRE(packed != nullptr, "pack: packed buffer is NULL");
+    if (packed_bytes < pl.total * sizeof(float)) {
+        set_error("pack: buffer too small (%zu < %zu bytes)", packed_bytes, pl.total * sizeof(float));
+        return DYGNN_E_WORKSPACE;
+    }
+    if (int rc = pack_generic(d, pl, w, static_cast<float*>(packed), as_stream(stream))) return rc;
+    if (fused_supported(d))
+        if (int rc = pack_fused(d, pl, w, static_cast<float*>(packed), as_stream(stream))) return rc;
+    return DYGNN_OK;
+}
+
+extern "C" int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, const void* packed,
+                                       const dygnn_csr* csr, const float* node_feat, const float* edge_feat, const int64_t* src,
+                                       const int64_t* dst, const double* times, int64_t batch, float* out_src, float* out_dst,
+                                       void* workspace, size_t workspace_bytes, const dygnn_dygformer_taps* taps, int32_t impl,
+                                       dygnn_stream_t stream) {
+    if (int rc = check_config(cfg)) return rc;
+    const Dims d = make_dims(*cfg);
+    if (int rc = check_weights(d, w)) return rc;
+    DYGNN_REQUIRE(csr && csr->indptr && csr->num_nodes >= 1, "forward: bad csr");
+    DYGNN_REQUIRE(batch >= 0, "forward: negative batch");
+    DYGNN_REQUIRE(packed && node_feat && edge_feat, "forward: null table / packed pointer");
+    DYGNN_REQUIRE(batch == 0 || (src && dst && times && out_src && out_dst && workspace), "forward: null pointer");
+    DYGNN_REQUIRE(impl >= 0 && impl <= 2, "forward: impl must be 0 (auto), 1 (generic) or 2 (fused)");
+    if (batch == 0) return DYGNN_OK;
+    const WorkspaceLayout wl = make_workspace_layout(d, batch);
+    if (workspace_bytes < wl.total) {
+        set_error("forward: workspace too small (%zu < %zu bytes)", workspace_bytes, wl.total);
+        return DYGNN_E_WORKSPACE;
+    }
+    const PackedLayout pl = make_packed_layout(d);
+    const bool can_fuse = fused_supported(d);
+    if (impl == 2 && !can_fuse) {
+        set_error("forward: fused kernel does not support this shape (D=%d H=%d tokens<=%d)", d.D, d.H, d.Tmax);
+        return DYGNN_E_UNSUPPORTED;
+    }
+    const bool use_fused = (impl == 2) || (impl == 0 && can_fuse);
+    auto fn = use_fused ? forward_fused : forward_generic;
+    return fn(d, pl, w, static_cast<const float*>(packed), csr, node_feat, edge_feat, src, dst, times, batch, out_src, out_dst,
+              static_cast<char*>(workspace), wl, taps, as_stream(stream));
+}
+
+extern "C" int dygnn_merge_layer_sigmoid(const float* a, const float* b, int64_t n, int32_t dim, int32_t hidden,
+                                         const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
+                                         float* out, dygnn_stream_t stream) {
+    DYGNN_REQUIRE(n >= 0 && dim > 0 && hidden > 0, "merge_layer: bad sizes");
+    DYGNN_REQUIRE(n == 0 || (a && b && fc1_w && fc1_b && fc2_w && fc2_b && out), "merge_layer: null pointer");
+    if (n == 0) return DYGNN_OK;
+    const size_t lds = (size_t)(2 * dim + 4) * sizeof(float);
+    DYGNN_REQUIRE(lds <= 64 * 1024, "merge_layer: dim too large");
+    hipLaunchKernelGGL(k_merge_sigmoid, dim3((unsigned)n), dim3(256), lds, as_stream(stream), a, b, dim, hidden, fc1_w, fc1_b, fc2_w,
+                       fc2_b, out);
+    DYGNN_LAUNCH_CHECK();
+    return DYGNN_OK;
+}

@@ -1,0 +1,221 @@
+"""Drop-in for the reference `DyGFormer` backbone (models/DyGFormer.py:11-317): same constructor,
+same `compute_src_dst_node_temporal_embeddings` / `set_neighbor_sampler` signatures, same
+parameter names and shapes (so `state_dict` round-trips with reference checkpoints) — but the whole
+forward (neighbour windows, co-occurrence counts, feature gathers, time encoding, patch
+projection, both encoder layers, pooling, output layer) runs inside libdygnn_hip.so with no host
+round trip: the reference's numpy hop (sampling/padding/counting on the host CPU,
+models/DyGFormer.py:78-106) disappears and ids never leave the GPU.
+
+Round-1 scope: inference forward (eval mode / no_grad — exactly what
+evaluate_models_utils.py:41-45 sets up).  The training-mode forward (dropout) and the backward
+pass are SURVEY.md §8f-1 and raise NotImplementedError instead of silently detaching.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import MultiheadAttention
+
+from . import _capi
+from .modules import TimeEncoder
+from .neighbor_sampler import NeighborSampler
+
+
+class NeighborCooccurrenceEncoder(nn.Module):
+    """Parameters of models/DyGFormer.py:320-335 (Linear(1,C) -> ReLU -> Linear(C,C))."""
+
+    def __init__(self, neighbor_co_occurrence_feat_dim: int, device: str = "cpu"):
+        super().__init__()
+        self.neighbor_co_occurrence_feat_dim = neighbor_co_occurrence_feat_dim
+        self.device = device
+        self.neighbor_co_occurrence_encode_layer = nn.Sequential(
+            nn.Linear(in_features=1, out_features=neighbor_co_occurrence_feat_dim),
+            nn.ReLU(),
+            nn.Linear(in_features=neighbor_co_occurrence_feat_dim, out_features=neighbor_co_occurrence_feat_dim))
+
+
+class TransformerEncoder(nn.Module):
+    """Parameters of models/DyGFormer.py:418-440 (pre-LN encoder layer)."""
+
+    def __init__(self, attention_dim: int, num_heads: int, dropout: float = 0.1):
+        super().__init__()
+        self.multi_head_attention = MultiheadAttention(embed_dim=attention_dim, num_heads=num_heads, dropout=dropout)
+        self.dropout = nn.Dropout(dropout)
+        self.linear_layers = nn.ModuleList([nn.Linear(attention_dim, 4 * attention_dim), nn.Linear(4 * attention_dim, attention_dim)])
+        self.norm_layers = nn.ModuleList([nn.LayerNorm(attention_dim), nn.LayerNorm(attention_dim)])
+
+
+class DyGFormer(nn.Module):
+
+    def __init__(self, node_raw_features: np.ndarray, edge_raw_features: np.ndarray, neighbor_sampler: NeighborSampler,
+                 time_feat_dim: int, channel_embedding_dim: int, patch_size: int = 1, num_layers: int = 2, num_heads: int = 2,
+                 dropout: float = 0.1, max_input_sequence_length: int = 512, device: str = "cpu"):
+        super().__init__()
+        # plain attributes, not buffers: they are not part of the state_dict (models/DyGFormer.py:32-33)
+        self.node_raw_features = torch.from_numpy(np.ascontiguousarray(node_raw_features, dtype=np.float32)).to(device)
+        self.edge_raw_features = torch.from_numpy(np.ascontiguousarray(edge_raw_features, dtype=np.float32)).to(device)
+
+        self.neighbor_sampler = neighbor_sampler
+        self.node_feat_dim = self.node_raw_features.shape[1]
+        self.edge_feat_dim = self.edge_raw_features.shape[1]
+        self.time_feat_dim = time_feat_dim
+        self.channel_embedding_dim = channel_embedding_dim
+        self.patch_size = patch_size
+        self.num_layers = num_layers
+        self.num_heads = num_heads
+        self.dropout = dropout
+        self.max_input_sequence_length = max_input_sequence_length
+        self.device = device
+
+        # same construction order as the reference => same default-init RNG stream per seed
+        self.time_encoder = TimeEncoder(time_dim=time_feat_dim)
+        self.neighbor_co_occurrence_feat_dim = self.channel_embedding_dim
+        self.neighbor_co_occurrence_encoder = NeighborCooccurrenceEncoder(self.neighbor_co_occurrence_feat_dim, device=self.device)
+        self.projection_layer = nn.ModuleDict({
+            "node": nn.Linear(self.patch_size * self.node_feat_dim, self.channel_embedding_dim, bias=True),
+            "edge": nn.Linear(self.patch_size * self.edge_feat_dim, self.channel_embedding_dim, bias=True),
+            "time": nn.Linear(self.patch_size * self.time_feat_dim, self.channel_embedding_dim, bias=True),
+            "neighbor_co_occurrence": nn.Linear(self.patch_size * self.neighbor_co_occurrence_feat_dim, self.channel_embedding_dim, bias=True),
+        })
+        self.num_channels = 4
+        self.transformers = nn.ModuleList([
+            TransformerEncoder(attention_dim=self.num_channels * self.channel_embedding_dim, num_heads=self.num_heads, dropout=self.dropout)
+            for _ in range(self.num_layers)])
+        self.output_layer = nn.Linear(self.num_channels * self.channel_embedding_dim, self.node_feat_dim, bias=True)
+
+        self._lib = _capi.load()           # fails loudly when the HIP library is missing
+        self._cfg = _capi.DygformerConfig(self.node_feat_dim, self.edge_feat_dim, self.time_feat_dim, self.channel_embedding_dim,
+                                          self.patch_size, self.num_layers, self.num_heads, self.max_input_sequence_length)
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_key = None
+        self._workspace: Dict[tuple, torch.Tensor] = {}
+        self.impl = 0                      # 0 auto, 1 generic, 2 fused (see include/dygnn.h)
+
+    # ---- reference API -------------------------------------------------------------------------
+    def set_neighbor_sampler(self, neighbor_sampler: NeighborSampler):
+        """models/DyGFormer.py:308-317."""
+        self.neighbor_sampler = neighbor_sampler
+        if self.neighbor_sampler.sample_neighbor_strategy in ["uniform", "time_interval_aware"]:
+            assert self.neighbor_sampler.seed is not None
+            self.neighbor_sampler.reset_random_state()
+
+    def compute_src_dst_node_temporal_embeddings(self, src_node_ids, dst_node_ids, node_interact_times,
+                                                 _taps: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """models/DyGFormer.py:68-194.  ndarray (or already-resident device tensor) [B] int64, [B] int64,
+        [B] float64 -> two float32 tensors [B, node_feat_dim] on the model's device."""
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("training-mode forward / backward through the HIP path is not built yet "
+                                      "(SURVEY.md §8f-1); call under model.eval() + torch.no_grad()")
+        dev = self._device()
+        src = self._to_dev(src_node_ids, torch.int64, dev)
+        dst = self._to_dev(dst_node_ids, torch.int64, dev)
+        tms = self._to_dev(node_interact_times, torch.float64, dev)
+        B = src.numel()
+        if not (dst.numel() == B and tms.numel() == B):
+            raise AssertionError("src_node_ids, dst_node_ids and node_interact_times must have the same length")
+        out_src = torch.empty((B, self.node_feat_dim), dtype=torch.float32, device=dev)
+        out_dst = torch.empty_like(out_src)
+        if B == 0:
+            return out_src, out_dst
+        weights = self._weights_struct()
+        packed = self._packed_weights(weights, dev)
+        ws = self._workspace_for(B, dev)
+        taps_struct = None
+        if _taps is not None:
+            taps_struct = self._make_taps(_taps, B, dev)
+        csr = self.neighbor_sampler.csr.on_device(dev)
+        rc = self._lib.dygnn_dygformer_forward(
+            C.byref(self._cfg), C.byref(weights), packed.data_ptr(), csr,
+            self.node_raw_features.data_ptr(), self.edge_raw_features.data_ptr(),
+            src.data_ptr(), dst.data_ptr(), tms.data_ptr(), B, out_src.data_ptr(), out_dst.data_ptr(),
+            ws.data_ptr(), ws.numel(), C.byref(taps_struct) if taps_struct is not None else None,
+            int(self.impl), _capi.current_stream_ptr())
+        _capi.check(rc)
+        return out_src, out_dst
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    def _device(self) -> torch.device:
+        dev = self.output_layer.weight.device
+        if dev.type != "cuda":
+            raise _capi.DygnnError("dyglib_amd.DyGFormer runs on an MI355X only: move the model to a GPU "
+                                   "(convert_to_gpu / .to('cuda')); there is no CPU fallback")
+        if self.node_raw_features.device != dev:      # the reference places the tables at construction
+            self.node_raw_features = self.node_raw_features.to(dev)
+            self.edge_raw_features = self.edge_raw_features.to(dev)
+        return dev
+
+    @staticmethod
+    def _to_dev(x, dtype, dev) -> torch.Tensor:
+        if isinstance(x, torch.Tensor):
+            return x.to(device=dev, dtype=dtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(x, dtype={torch.int64: np.int64, torch.float64: np.float64}[dtype])).to(dev, non_blocking=True)
+
+    def _weights_struct(self) -> "_capi.DygformerWeights":
+        w = _capi.DygformerWeights()
+        p = lambda t: t.data_ptr()
+        enc = self.neighbor_co_occurrence_encoder.neighbor_co_occurrence_encode_layer
+        w.time_w, w.time_b = p(self.time_encoder.w.weight), p(self.time_encoder.w.bias)
+        w.cooc_w0, w.cooc_b0, w.cooc_w1, w.cooc_b1 = p(enc[0].weight), p(enc[0].bias), p(enc[2].weight), p(enc[2].bias)
+        pl = self.projection_layer
+        w.proj_node_w, w.proj_node_b = p(pl["node"].weight), p(pl["node"].bias)
+        w.proj_edge_w, w.proj_edge_b = p(pl["edge"].weight), p(pl["edge"].bias)
+        w.proj_time_w, w.proj_time_b = p(pl["time"].weight), p(pl["time"].bias)
+        w.proj_cooc_w, w.proj_cooc_b = p(pl["neighbor_co_occurrence"].weight), p(pl["neighbor_co_occurrence"].bias)
+        for l, tr in enumerate(self.transformers):
+            L = w.layers[l]
+            mha = tr.multi_head_attention
+            L.in_proj_weight, L.in_proj_bias = p(mha.in_proj_weight), p(mha.in_proj_bias)
+            L.out_proj_weight, L.out_proj_bias = p(mha.out_proj.weight), p(mha.out_proj.bias)
+            L.ffn0_weight, L.ffn0_bias = p(tr.linear_layers[0].weight), p(tr.linear_layers[0].bias)
+            L.ffn1_weight, L.ffn1_bias = p(tr.linear_layers[1].weight), p(tr.linear_layers[1].bias)
+            L.norm0_weight, L.norm0_bias = p(tr.norm_layers[0].weight), p(tr.norm_layers[0].bias)
+            L.norm1_weight, L.norm1_bias = p(tr.norm_layers[1].weight), p(tr.norm_layers[1].bias)
+        w.output_w, w.output_b = p(self.output_layer.weight), p(self.output_layer.bias)
+        return w
+
+    def _packed_weights(self, weights, dev) -> torch.Tensor:
+        """Kernel-ready weight copy; re-packed whenever any parameter was written (optimizer step,
+        load_state_dict) — detected through the tensors' version counters and addresses."""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(dev),)
+        if self._packed is None or self._packed_key != key:
+            for p in self.parameters():
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise _capi.DygnnError("parameters must be contiguous float32")
+            nbytes = self._lib.dygnn_dygformer_packed_bytes(C.byref(self._cfg))
+            if nbytes == 0:
+                _capi.check(-1)
+            if self._packed is None or self._packed.numel() != nbytes or self._packed.device != dev:
+                self._packed = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            _capi.check(self._lib.dygnn_dygformer_pack(C.byref(self._cfg), C.byref(weights), self._packed.data_ptr(), nbytes,
+                                                       _capi.current_stream_ptr()))
+            self._packed_key = key
+        return self._packed
+
+    def _workspace_for(self, B: int, dev) -> torch.Tensor:
+        # one workspace per (batch size, stream): calls issued on different HIP streams may overlap
+        key = (B, torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._workspace.get(key)
+        if ws is None or ws.device != dev:
+            nbytes = self._lib.dygnn_dygformer_workspace_bytes(C.byref(self._cfg), B)
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            if len(self._workspace) > 16:
+                self._workspace.clear()
+            self._workspace[key] = ws
+        return ws
+
+    def _make_taps(self, taps: dict, B: int, dev) -> "_capi.DygformerTaps":
+        P, L, D = self.patch_size, self.max_input_sequence_length, self.num_channels * self.channel_embedding_dim
+        t_max = 2 * ((L + P - 1) // P)
+        taps["seq_lens"] = torch.zeros(2, dtype=torch.int32, device=dev)
+        taps["encoder_input"] = torch.zeros((B, t_max, D), dtype=torch.float32, device=dev)
+        taps["layer_outputs"] = [torch.zeros((B, t_max, D), dtype=torch.float32, device=dev) for _ in range(self.num_layers)]
+        s = _capi.DygformerTaps()
+        s.seq_lens = taps["seq_lens"].data_ptr()
+        s.encoder_input = taps["encoder_input"].data_ptr()
+        for l in range(self.num_layers):
+            s.layer_out[l] = taps["layer_outputs"][l].data_ptr()
+        return s

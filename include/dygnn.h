@@ -1,0 +1,174 @@
+/*
+ * dygnn.h — C ABI of libdygnn_hip.so: MI355X (gfx950) kernels for DyGLib's
+ * temporal-neighbour-aggregation hot path.
+ *
+ * The reference (webster-781/DyGLib) is pure Python and has no FFI: its boundary for this
+ * path is the duck-typed Python interface of utils/utils.py:71-302 (NeighborSampler) and
+ * models/DyGFormer.py:11-317 (DyGFormer).  This header is what a binding for that path
+ * binds; every entry point cites the reference code it replaces.  INTEGRATION.md shows the
+ * ctypes stub and the two-line change to train_link_prediction.py.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / HIP types in the signatures (dygnn_stream_t is a
+ *     hipStream_t passed as void*; NULL = the null stream);
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in _host;
+ *   - no allocation and no host synchronisation inside any *device* entry point: callers pass
+ *     workspaces sized by the *_bytes() helpers, so calls can be captured in a hipGraph;
+ *   - return value: 0 = ok, <0 = error (DYGNN_E_*); dygnn_last_error() returns a message for
+ *     the calling thread.  Invalid arguments map to the reference's AssertionError sites,
+ *     e.g. k <= 0 (utils/utils.py:157) or max_input_sequence_length <= 1 (DyGFormer.py:209).
+ */
+#ifndef DYGNN_H
+#define DYGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DYGNN_OK            0
+#define DYGNN_E_INVALID    -1   /* bad argument (reference: AssertionError / ValueError)   */
+#define DYGNN_E_HIP        -2   /* HIP runtime error (launch failure, bad pointer ...)     */
+#define DYGNN_E_UNSUPPORTED -3  /* shape outside what the kernels were built for           */
+#define DYGNN_E_WORKSPACE  -4   /* caller workspace too small                              */
+
+#define DYGNN_MAX_LAYERS 8
+
+typedef void* dygnn_stream_t;   /* hipStream_t */
+
+const char* dygnn_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int dygnn_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Temporal CSR: the time-sorted adjacency of NeighborSampler.__init__ (utils/utils.py:73-110)
+ * built from an interaction list by get_neighbor_sampler (utils/utils.py:283-302).
+ * Row r = node id r; row 0 = padding node, empty.  Inside a row entries ascend in time, ties
+ * in edge-list order (stable sort, utils/utils.py:98-100).  Undirected: each interaction is
+ * stored under both endpoints (utils/utils.py:298-300), src entry first.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dygnn_csr {
+    int64_t        num_nodes;    /* rows = max node id + 1                                  */
+    int64_t        num_entries;  /* 2 * number of interactions                              */
+    const int64_t* indptr;       /* [num_nodes + 1]                                         */
+    const int32_t* nbr;          /* [num_entries] neighbour node id                         */
+    const int32_t* eid;          /* [num_entries] edge id                                   */
+    const double*  ts;           /* [num_entries] interaction time (float64, as stored)     */
+} dygnn_csr;
+
+/* Host-side builder (C++, no GPU needed).  Inputs: the four parallel arrays of `Data`
+ * (utils/DataLoader.py:46-64).  Outputs: caller-allocated host arrays of the sizes above with
+ * num_nodes = max(src,dst)+1.  Replaces utils/utils.py:283-302 + :96-103. */
+int dygnn_csr_build_host(int64_t num_edges, const int64_t* src_host, const int64_t* dst_host,
+                         const int64_t* eid_host, const double* ts_host, int64_t num_nodes,
+                         int64_t* indptr_host, int32_t* nbr_host, int32_t* eid_out_host, double* ts_out_host);
+
+/* find_neighbors_before for n queries (utils/utils.py:130-147): hist_len[q] = i =
+ * searchsorted(times[node], t, side='left') and end_pos[q] = indptr[node] + i (absolute CSR
+ * index one past the last strictly-earlier interaction).  Either output may be NULL. */
+int dygnn_find_neighbors_before(const dygnn_csr* csr_host, const int64_t* nodes, const double* times, int64_t n,
+                                int32_t* hist_len, int64_t* end_pos, dygnn_stream_t stream);
+
+/* get_historical_neighbors, strategy 'recent' (utils/utils.py:149-214, branch :200-209):
+ * most recent k strictly-earlier interactions, RIGHT-aligned, zero-filled at the front.
+ * Outputs [n,k]: int64 ids, int64 edge ids, float32 times (dtypes of utils/utils.py:161-167). */
+int dygnn_sample_recent(const dygnn_csr* csr_host, const int64_t* nodes, const double* times, int64_t n, int32_t k,
+                        int64_t* out_nbr, int64_t* out_eid, float* out_ts, dygnn_stream_t stream);
+
+/* DyGFormer window, phase 1 (get_all_first_hop_neighbors utils/utils.py:254-273 + the length
+ * scan of pad_sequences models/DyGFormer.py:210-220): per query hist_len / end_pos as above and
+ * *max_window = max_q min(hist_len[q], L-1) (device int32, overwritten).  The padded length is
+ * S = roundup(*max_window + 1, patch_size) (models/DyGFormer.py:223-226). */
+int dygnn_window_lengths(const dygnn_csr* csr_host, const int64_t* nodes, const double* times, int64_t n,
+                         int32_t max_input_sequence_length, int32_t* hist_len, int64_t* end_pos,
+                         int32_t* max_window, dygnn_stream_t stream);
+
+/* DyGFormer window, phase 2 (pad_sequences models/DyGFormer.py:228-245): [n,S] LEFT-aligned
+ * rows: col 0 = (node, edge 0, float32(t)); cols 1..m = the most recent m = min(hist_len, L-1)
+ * interactions oldest->newest; zeros after.  int64 / int64 / float32 as :230-232. */
+int dygnn_window_fill(const dygnn_csr* csr_host, const int64_t* nodes, const double* times, int64_t n,
+                      int32_t max_input_sequence_length, int32_t S, const int32_t* hist_len, const int64_t* end_pos,
+                      int64_t* out_ids, int64_t* out_eids, float* out_ts, dygnn_stream_t stream);
+
+/* NeighborCooccurrenceEncoder.count_nodes_appearances (models/DyGFormer.py:337-393):
+ * src_ids [n,S_s], dst_ids [n,S_d] int64 -> cnt_src [n,S_s,2], cnt_dst [n,S_d,2] float32 holding
+ * [count in src row, count in dst row]; positions with id 0 give [0,0]. */
+int dygnn_cooccurrence(const int64_t* src_ids, const int64_t* dst_ids, int64_t n, int32_t S_s, int32_t S_d,
+                       float* cnt_src, float* cnt_dst, dygnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DyGFormer.compute_src_dst_node_temporal_embeddings (models/DyGFormer.py:68-194), eval mode.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dygnn_dygformer_config {
+    int32_t node_feat_dim;              /* F_n (172)                         DyGFormer.py:36 */
+    int32_t edge_feat_dim;              /* F_e (172)                         DyGFormer.py:37 */
+    int32_t time_feat_dim;              /* F_t (100)                         DyGFormer.py:38 */
+    int32_t channel_embedding_dim;      /* C (50); model dim D = 4C          DyGFormer.py:39 */
+    int32_t patch_size;                 /* P                                 DyGFormer.py:40 */
+    int32_t num_layers;                 /* <= DYGNN_MAX_LAYERS               DyGFormer.py:41 */
+    int32_t num_heads;                  /* H, D % H == 0                     DyGFormer.py:42 */
+    int32_t max_input_sequence_length;  /* L                                 DyGFormer.py:44 */
+} dygnn_dygformer_config;
+
+/* Raw parameter pointers in PyTorch layout (row-major [out,in]); names = state_dict keys
+ * (SURVEY.md Appendix A). */
+typedef struct dygnn_encoder_layer_weights {
+    const float *in_proj_weight, *in_proj_bias;      /* [3D,D],[3D]  multi_head_attention     */
+    const float *out_proj_weight, *out_proj_bias;    /* [D,D],[D]                             */
+    const float *ffn0_weight, *ffn0_bias;            /* [4D,D],[4D]  linear_layers.0          */
+    const float *ffn1_weight, *ffn1_bias;            /* [D,4D],[D]   linear_layers.1          */
+    const float *norm0_weight, *norm0_bias;          /* [D]          norm_layers.0            */
+    const float *norm1_weight, *norm1_bias;          /* [D]          norm_layers.1            */
+} dygnn_encoder_layer_weights;
+
+typedef struct dygnn_dygformer_weights {
+    const float *time_w, *time_b;                    /* [F_t,1],[F_t] time_encoder.w          */
+    const float *cooc_w0, *cooc_b0;                  /* [C,1],[C]    ..encode_layer.0         */
+    const float *cooc_w1, *cooc_b1;                  /* [C,C],[C]    ..encode_layer.2         */
+    const float *proj_node_w, *proj_node_b;          /* [C,P*F_n],[C]                         */
+    const float *proj_edge_w, *proj_edge_b;          /* [C,P*F_e],[C]                         */
+    const float *proj_time_w, *proj_time_b;          /* [C,P*F_t],[C]                         */
+    const float *proj_cooc_w, *proj_cooc_b;          /* [C,P*C],[C]                           */
+    dygnn_encoder_layer_weights layers[DYGNN_MAX_LAYERS];
+    const float *output_w, *output_b;                /* [F_n,D],[F_n] output_layer            */
+} dygnn_dygformer_weights;
+
+/* Optional stage taps for parity tests (any member may be NULL).  Row-major, token stride
+ * T_max = 2*ceil(L/P):  encoder_input / layer_out[l] are [B, T_max, D]. */
+typedef struct dygnn_dygformer_taps {
+    int32_t* seq_lens;                               /* [2]: S_src, S_dst                     */
+    float*   encoder_input;
+    float*   layer_out[DYGNN_MAX_LAYERS];
+} dygnn_dygformer_taps;
+
+/* Kernel-ready copy of the weights (transposed / MFMA-fragment order, co-occurrence LUT).
+ * Re-pack after every optimizer step; packing is one cheap launch sequence. */
+size_t dygnn_dygformer_packed_bytes(const dygnn_dygformer_config* cfg_host);
+int dygnn_dygformer_pack(const dygnn_dygformer_config* cfg_host, const dygnn_dygformer_weights* w_host,
+                         void* packed, size_t packed_bytes, dygnn_stream_t stream);
+
+size_t dygnn_dygformer_workspace_bytes(const dygnn_dygformer_config* cfg_host, int64_t batch);
+
+/* impl: 0 = auto (fused MFMA kernel when the shape is supported, else generic),
+ *       1 = generic multi-kernel path (any shape), 2 = fused kernel (error if unsupported). */
+int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg_host, const dygnn_dygformer_weights* w_host,
+                            const void* packed, const dygnn_csr* csr_host,
+                            const float* node_feat, const float* edge_feat,
+                            const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
+                            float* out_src, float* out_dst,
+                            void* workspace, size_t workspace_bytes,
+                            const dygnn_dygformer_taps* taps_host, int32_t impl, dygnn_stream_t stream);
+
+/* Caller-side link predictor, fused: sigmoid(MergeLayer(a,b)) with
+ * MergeLayer = fc2(relu(fc1(cat(a,b)))) (models/modules.py:57-68; evaluate_models_utils.py:140-141).
+ * a,b [n,dim]; fc1 [hidden, 2*dim]; fc2 [1,hidden]; out [n]. */
+int dygnn_merge_layer_sigmoid(const float* a, const float* b, int64_t n, int32_t dim, int32_t hidden,
+                              const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
+                              float* out, dygnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYGNN_H */
