@@ -174,8 +174,19 @@ def _t(params: Dict[str, np.ndarray], key: str) -> torch.Tensor:
 
 
 def time_encode(params, dt: torch.Tensor) -> torch.Tensor:
-    """models/modules.py:27-39: cos(Linear(1,F_t)(dt))."""
-    return torch.cos(F.linear(dt.unsqueeze(-1), _t(params, "time_encoder.w.weight"), _t(params, "time_encoder.w.bias")))
+    """models/modules.py:27-39: cos(Linear(1,F_t)(dt)).
+
+    The K=1 Linear is one multiply-add per element, and dt reaches ~2.7e6 s where one float32 ulp is
+    0.25 rad: whether the host BLAS rounds the product before adding the bias changes cos() by up to
+    0.25.  In the build container PyTorch's CPU addmm fuses it (bit-identical to fma(dt, w, b) on 320k
+    samples, and what the golden vectors hold); other hosts' BLAS kernels do not.  The oracle therefore
+    states the fused form explicitly so it gives the golden values on every host: the float64
+    product of two float32 is exact, so float32(float64(dt)*w + b) is the single-rounding fma
+    (up to a double rounding of the sum that cannot exceed one float32 ulp in ~1e-7 of the cases)."""
+    w = _t(params, "time_encoder.w.weight").reshape(-1).double()
+    b = _t(params, "time_encoder.w.bias").double()
+    pre = (dt.double().unsqueeze(-1) * w + b).float()
+    return torch.cos(pre)
 
 
 def cooccurrence_features(params, counts: torch.Tensor) -> torch.Tensor:
