@@ -26,6 +26,13 @@ CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-W
             "-ffp-contract=off"]   # contractions are written explicitly (fmaf) where the oracle has them
 
 
+VARIANTS = {"": [], "stamps": ["-DDYGNN_STAMPS=1"], "noload": ["-DDYGNN_STAMPS=1", "-DDYGNN_ABLATE_NOLOAD=1"]}
+
+
+def lib_path(variant: str = "") -> str:
+    return LIB_PATH if not variant else os.path.join(CSRC, f"libdygnn_hip_{variant}.so")
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
         if cand and os.path.exists(cand):
@@ -44,9 +51,9 @@ def _digest() -> str:
     return h.hexdigest()
 
 
-def _compile(src: str, obj_dir: str) -> str:
+def _compile(src: str, obj_dir: str, extra=()) -> str:
     obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
-    cmd = [_hipcc(), *CXXFLAGS, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [_hipcc(), *CXXFLAGS, *extra, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
     if src.endswith(".cpp"):
         cmd.insert(1, "-x"), cmd.insert(2, "hip")
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -57,25 +64,28 @@ def _compile(src: str, obj_dir: str) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    stamp = os.path.join(CSRC, "build", "digest.txt")
+def build(force: bool = False, verbose: bool = True, variant: str = "") -> str:
+    out = lib_path(variant)
+    obj_dir = os.path.join(CSRC, "build" + ("_" + variant if variant else ""))
+    stamp = os.path.join(obj_dir, "digest.txt")
     digest = _digest()
-    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read() == digest:
-        return LIB_PATH
-    obj_dir = os.path.join(CSRC, "build")
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return out
     os.makedirs(obj_dir, exist_ok=True)
     with cf.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
-        objs: List[str] = list(ex.map(lambda s: _compile(s, obj_dir), SOURCES))
-    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB_PATH]
+        objs: List[str] = list(ex.map(lambda s: _compile(s, obj_dir, VARIANTS[variant]), SOURCES))
+    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     with open(stamp, "w") as f:
         f.write(digest)
     if verbose:
-        print(f"built {LIB_PATH}")
-    return LIB_PATH
+        print(f"built {out}")
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    variants = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")] or [""]
+    for v in variants:
+        build(force="--force" in sys.argv, variant=v)

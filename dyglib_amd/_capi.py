@@ -53,7 +53,8 @@ class DygformerWeights(C.Structure):
 
 
 class DygformerTaps(C.Structure):
-    _fields_ = [("seq_lens", C.c_void_p), ("encoder_input", C.c_void_p), ("layer_out", C.c_void_p * DYGNN_MAX_LAYERS)]
+    _fields_ = [("seq_lens", C.c_void_p), ("encoder_input", C.c_void_p), ("layer_out", C.c_void_p * DYGNN_MAX_LAYERS),
+                ("phase_cycles", C.c_void_p)]
 
 
 # name -> (restype, argtypes).  Every symbol include/dygnn.h declares; tests check the export list.
@@ -88,7 +89,8 @@ _lib: Optional[C.CDLL] = None
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    # DYGNN_LIB_VARIANT=stamps selects the diagnostic build with in-kernel phase stamps (tools/phase_profile.py)
+    return _build.lib_path(os.environ.get("DYGNN_LIB_VARIANT", ""))
 
 
 def load() -> C.CDLL:
@@ -99,7 +101,7 @@ def load() -> C.CDLL:
     path = lib_path()
     if not os.path.exists(path):
         try:
-            _build.build(verbose=False)
+            _build.build(verbose=False, variant=os.environ.get("DYGNN_LIB_VARIANT", ""))
         except Exception as e:  # no hipcc, or compile error: fail loudly, never fall back
             raise DygnnError(f"{path} is missing and could not be built: {e}") from e
     lib = C.CDLL(path)

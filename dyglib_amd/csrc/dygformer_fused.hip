@@ -36,6 +36,7 @@ constexpr int kBufFloats = kTok * kXS;                 // 13056 floats = 52224 B
 constexpr int kLdsXn = 0, kLdsK = kBufFloats, kLdsV = 2 * kBufFloats, kLdsMisc = 3 * kBufFloats;
 constexpr int kLdsBytes = 160 * 1024;
 constexpr int kFrag = 256;     // floats per packed 16x16 fragment
+constexpr int kFfnGroups0 = 6; // FFN hidden groups (of 5 tiles) given to half 0; half 1 takes the other 10 - kFfnGroups0
 
 __device__ __forceinline__ f4 mfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -86,17 +87,56 @@ __device__ __forceinline__ void mma_all_ntiles(f4 (&y)[13], const float* wfrag, 
 __device__ __forceinline__ f4 ldg4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ f4 lds4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ f4 zero4() { return f4{0.f, 0.f, 0.f, 0.f}; }
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// A wave's weight fragments arrive as ONE linear stream in consumption order (see pack_fused): a ring of
+// R fragments stays in flight, each take() returns the oldest and immediately re-issues that slot R
+// fragments ahead, so the L2 latency of every 1-KiB fragment read hides behind R*4 MFMAs.  Slot indices are
+// compile-time constants after unrolling (register arrays cannot be indexed at run time).
+template <int R>
+struct FragStream {
+    const float* p;
+    f4 ring[R];
+    __device__ __forceinline__ void open(const float* base, int lane) {
+        p = base + lane * 4;
+#pragma unroll
+        for (int u = 0; u < R; ++u) ring[u] = *reinterpret_cast<const f4*>(p + u * kFrag);
+        p += R * kFrag;
+    }
+    __device__ __forceinline__ f4 take(int slot) {
+        const f4 v = ring[slot];
+#ifndef DYGNN_ABLATE_NOLOAD          // ablation build: never refill (wrong results, times the pure MFMA structure)
+        ring[slot] = *reinterpret_cast<const f4*>(p);
+        p += kFrag;
+#else
+        asm volatile("" : "+v"(ring[slot]));
+#endif
+        return v;
+    }
+};
+
+// erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7 over the reals), branch-free: one v_rcp, one v_exp and
+// five fma instead of the ~60-instruction two-branch libm erff.  The reference's GELU is the exact-erf form
+// (F.gelu default, models/DyGFormer.py:458); the approximation error enters the output at < 1e-6, two orders
+// below the 1e-4 parity tolerance, and the 51,200 GELUs per pair and layer stop being an MFMA-idle phase.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __expf(-ax * ax);
+    return copysignf(fmaf(-p * t, e, 1.0f), x);
+}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f)); }
 
 struct FusedLayer {
     const float *ln0g, *ln0b, *ln1g, *ln1b;   // [208] zero padded
-    const float* wqkv;                        // [39 tiles][13 chunks][256]  tiles: Q 0..12, K 13..25, V 26..38
-    const float* bqkv;                        // [39*16]
-    const float* wo;                          // [2 heads][13 n-tiles][7 d-chunks][256]
+    const float* wqkv[2];                     // per half: stream [13 chunks][20 tiles][256]
+    const float* bqkv[2];                     // per half: [20 tiles * 16]
+    const float* wo[2];                       // per head: stream [7 d-chunks][13 n-tiles][256]
     const float* bo;                          // [208]
-    const float* w1;                          // [50 hidden tiles][13 chunks][256]
+    const float* wffn[2];                     // per half: 5 groups x { [13 chunks][5 hidden tiles] , [5 hidden][13 n-tiles] } x [256]
     const float* b1;                          // [800]
-    const float* w2;                          // [50 hidden chunks][13 n-tiles][256]
     const float* b2;                          // [208]
 };
 
@@ -107,15 +147,16 @@ struct FusedArgs {
     const int32_t* hist_len; const int64_t* end_pos; const CallDims* cd;
     // tables + small weights
     const float *node_feat, *edge_feat, *time_w, *time_b, *lut;
-    const float* proj[4];       // per channel: [4 tiles][nchunk_ch][256]
+    const float* proj[5];       // streams [nchunk_pad][tiles of this half][256]: h0c0, h0c1, h0c2, h1c2, h1c3
     const float* bias_x;        // [208] projection biases in model-dim order
     FusedLayer layer[DYGNN_MAX_LAYERS];
     const float *outT, *outb;   // output layer: transposed [200][Fn], bias [Fn]
     float *out_src, *out_dst;
     float* tap_enc; float* tap_layer[DYGNN_MAX_LAYERS];
+    unsigned long long* stamps;
     int64_t B;
     int Fn, Fe, Ft, P, L, NL, Tmax;
-    int nchunk[4];
+    int nchunk[4];              // per channel, padded to an even count
     float qscale;
 };
 
@@ -126,6 +167,14 @@ template <int NTILES>
 __device__ __forceinline__ void layernorm_to_lds(const f4 (&x)[7], float* lds, const float* gamma, const float* beta,
                                                  int tile0, int tt, int hf, int c, int g, int which) {
     float* st = lds + kLdsMisc + which * 256;      // [sum: 2*64][var: 2*64]
+    // scale / shift for this lane's rows: issued first so their latency hides behind the two reductions
+    f4 gm[NTILES], bt[NTILES];
+#pragma unroll
+    for (int i = 0; i < NTILES; ++i) {
+        const int n = 16 * (tile0 + i) + 4 * g;      // < 208: gamma/beta are zero-padded to 208
+        gm[i] = ldg4(gamma + n);
+        bt[i] = ldg4(beta + n);
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NTILES; ++i) s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
@@ -154,12 +203,11 @@ __device__ __forceinline__ void layernorm_to_lds(const f4 (&x)[7], float* lds, c
     for (int i = 0; i < NTILES; ++i) {
         const int n = 16 * (tile0 + i) + 4 * g;
         if (n < kXS) {
-            const f4 gm = ldg4(gamma + n), bt = ldg4(beta + n);
             f4 y;
-            y.x = (x[i].x - mean) * rstd * gm.x + bt.x;
-            y.y = (x[i].y - mean) * rstd * gm.y + bt.y;
-            y.z = (x[i].z - mean) * rstd * gm.z + bt.z;
-            y.w = (x[i].w - mean) * rstd * gm.w + bt.w;
+            y.x = (x[i].x - mean) * rstd * gm[i].x + bt[i].x;
+            y.y = (x[i].y - mean) * rstd * gm[i].y + bt[i].y;
+            y.z = (x[i].z - mean) * rstd * gm[i].z + bt[i].z;
+            y.w = (x[i].w - mean) * rstd * gm[i].w + bt[i].w;
             *reinterpret_cast<f4*>(row + n) = y;
         }
     }
@@ -195,26 +243,51 @@ __device__ __forceinline__ void tap_store(const f4 (&x)[7], float* base, int64_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// patch-projection of one channel into NT consecutive resident tiles x[LOCAL0 .. LOCAL0+NT)
-// bfn(kc) returns this lane's 4 feature values k = 16kc+4g .. +3 of its token
+// patch-projection of one channel into NTL consecutive resident tiles x[LOCAL0 .. LOCAL0+NTL)
+// bfn(kc) returns this lane's 4 feature values k = 16kc+4g .. +3 of its token; nchunk is even.
+// Two chunks per iteration: the gathers / fragment loads of chunks kc+2, kc+3 are in flight while
+// chunks kc, kc+1 are multiplied.
 // ------------------------------------------------------------------------------------------------
 template <int LOCAL0, int NTL, typename BF>
-__device__ __forceinline__ void project_channel(f4 (&x)[7], const float* wp, int first_pack_tile, int nchunk, int lane, BF bfn) {
-    for (int kc = 0; kc < nchunk; ++kc) {
-        const f4 b = bfn(kc);
-        f4 a[NTL];
+__device__ __forceinline__ void project_channel(f4 (&x)[7], const float* wstream, int nchunk, int lane, BF bfn) {
+    FragStream<2 * NTL> st;
+    st.open(wstream, lane);
+    f4 b0 = bfn(0), b1 = bfn(1);
+    for (int kc = 0; kc < nchunk; kc += 2) {
+        const f4 n0 = bfn(kc + 2), n1 = bfn(kc + 3);      // beyond the last chunk bfn returns zeros
+        f4 a0[NTL], a1[NTL];
 #pragma unroll
-        for (int i = 0; i < NTL; ++i) a[i] = ldg4(wp + ((size_t)(first_pack_tile + i) * nchunk + kc) * kFrag + lane * 4);
+        for (int i = 0; i < NTL; ++i) a0[i] = st.take(i);
 #pragma unroll
-        for (int i = 0; i < NTL; ++i) x[LOCAL0 + i] = mfma(a[i].x, b.x, x[LOCAL0 + i]);
-#pragma unroll
-        for (int i = 0; i < NTL; ++i) x[LOCAL0 + i] = mfma(a[i].y, b.y, x[LOCAL0 + i]);
-#pragma unroll
-        for (int i = 0; i < NTL; ++i) x[LOCAL0 + i] = mfma(a[i].z, b.z, x[LOCAL0 + i]);
-#pragma unroll
-        for (int i = 0; i < NTL; ++i) x[LOCAL0 + i] = mfma(a[i].w, b.w, x[LOCAL0 + i]);
+        for (int i = 0; i < NTL; ++i) a1[i] = st.take(NTL + i);
+        mma_group<NTL>(&x[LOCAL0], a0, b0);
+        mma_group<NTL>(&x[LOCAL0], a1, b1);
+        b0 = n0; b1 = n1;
     }
 }
+
+#ifdef DYGNN_STAMPS
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        if (a.stamps != nullptr && lane == 0 && blockIdx.x < 4)                                    \
+            a.stamps[((size_t)blockIdx.x * 8 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+#define TICK() __builtin_amdgcn_s_memtime()
+#define SUBT_DECL unsigned long long subt[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tk0 = 0
+#define SUBT_START() do { __builtin_amdgcn_sched_barrier(0); tk0 = TICK(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SUBT_ADD(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = TICK(); subt[i] += t_ - tk0; tk0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SUBT_STORE()                                                                               \
+    do {                                                                                           \
+        if (a.stamps != nullptr && lane == 0 && blockIdx.x < 4)                                    \
+            for (int i_ = 0; i_ < 6; ++i_) a.stamps[((size_t)blockIdx.x * 8 + wave) * 32 + 24 + i_] = subt[i_]; \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#define SUBT_DECL do { } while (0)
+#define SUBT_START() do { } while (0)
+#define SUBT_ADD(i) do { } while (0)
+#define SUBT_STORE() do { } while (0)
+#endif
 
 // ================================================================================================
 __global__ __launch_bounds__(512, 2) void k_dygformer_fused(const FusedArgs a) {
@@ -226,6 +299,8 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused(const FusedArgs a) {
     const int c = lane & 15, g = lane >> 4;
     const int64_t b = blockIdx.x;
 
+    STAMP(0);
+    SUBT_DECL;
     const CallDims cd = *a.cd;
     const int Ss = cd.S_s, Sd = cd.S_d, Ts = cd.T_s, T = cd.T;
     const int S = Ss + Sd;
@@ -270,6 +345,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused(const FusedArgs a) {
     }
     __syncthreads();
 
+    STAMP(1);
     // ---- resident residual stream X^T: tiles tile0 .. tile0+6 (hf=0) / +5 (hf=1) for tokens 16tt..16tt+15
     const int tile0 = hf ? 7 : 0;
     const bool active = 16 * tt < T;                 // wave-uniform: this token tile holds real tokens
@@ -316,14 +392,15 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused(const FusedArgs a) {
             return r;
         };
         if (hf == 0) {
-            project_channel<0, 4>(x, a.proj[0], 0, a.nchunk[0], lane, [&](int kc) { return gather(a.node_feat, ids, a.Fn, kc); });
-            project_channel<3, 4>(x, a.proj[1], 0, a.nchunk[1], lane, [&](int kc) { return gather(a.edge_feat, eids, a.Fe, kc); });
-            project_channel<6, 1>(x, a.proj[2], 0, a.nchunk[2], lane, timef);
+            project_channel<0, 4>(x, a.proj[0], a.nchunk[0], lane, [&](int kc) { return gather(a.node_feat, ids, a.Fn, kc); });
+            project_channel<3, 4>(x, a.proj[1], a.nchunk[1], lane, [&](int kc) { return gather(a.edge_feat, eids, a.Fe, kc); });
+            project_channel<6, 1>(x, a.proj[2], a.nchunk[2], lane, timef);
         } else {
-            project_channel<0, 3>(x, a.proj[2], 1, a.nchunk[2], lane, timef);
-            project_channel<2, 4>(x, a.proj[3], 0, a.nchunk[3], lane, coocf);
+            project_channel<0, 3>(x, a.proj[3], a.nchunk[2], lane, timef);
+            project_channel<2, 4>(x, a.proj[4], a.nchunk[3], lane, coocf);
         }
     }
+    STAMP(2);
     __syncthreads();     // everyone is done with ids/eids/dts/c0/c1 (they live in the V buffer)
     // re-zero the part of V that held the window arrays (rows of absent tokens must stay finite zeros)
     for (int i = tid; i < (5 * S + 3) / 4; i += 512) reinterpret_cast<f4*>(lds + kLdsV)[i] = zero4();
@@ -335,57 +412,58 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused(const FusedArgs a) {
 
     for (int l = 0; l < a.NL; ++l) {
         const FusedLayer& W = a.layer[l];
+        STAMP(3 + 8 * l);
         // ================= LN0 -> Xn =================
+        FragStream<5> sq;
+        sq.open(W.wqkv[hf], lane);          // first fragments fly while the LayerNorm runs
         if (hf == 0) layernorm_to_lds<7>(x, lds, W.ln0g, W.ln0b, tile0, tt, hf, c, g, 0);
         else layernorm_to_lds<6>(x, lds, W.ln0g, W.ln0b, tile0, tt, hf, c, g, 0);
         __syncthreads();
 
-        // ================= QKV =================
-        f4 qa[7];     // Q^T tiles 6hf .. 6hf+6 (rows outside head hf are zeroed below), already scaled
+        STAMP(4 + 8 * l);
+        // ================= QKV: 20 output tiles per wave, k-chunk outer, all accumulators resident =================
+        // tiles j: 0..6 = Q tiles 6hf..6hf+6 (kept in registers, scaled); then the K/V tiles of this half
+        // (hf=0 -> K 0..6, V 0..5 ; hf=1 -> K 7..12, V 6..12), written to LDS.
+        f4 qa[7];
+        FragStream<7> so;
         if (active) {
-            f4 bf[kKC];
-            load_bfrags(bf, Xn, tt, c, g);
-            // 20 tiles per wave, two at a time: Q tiles 6hf..6hf+6 (kept in registers, scaled), then the 13 K/V
-            // tiles of this half (hf=0 -> K 0..6, V 0..5 ; hf=1 -> K 7..12, V 6..12) written to LDS.
-            const int nk = hf ? 6 : 7, k_first = hf ? 7 : 0, v_first = hf ? 6 : 0;
-            auto kv_tile = [&](int s, int& ptile, float*& dbuf, int& ncol) {      // slot s in 0..12
-                const bool isk = s < nk;
-                const int tile = isk ? k_first + s : v_first + (s - nk);
-                ptile = (isk ? 13 : 26) + tile; dbuf = isk ? Kb : Vb; ncol = 16 * tile + 4 * g;
-            };
-            auto wq = [&](int ptile) { return W.wqkv + (size_t)ptile * kKC * kFrag; };
+            f4 acc[20];
 #pragma unroll
-            for (int j = 0; j < 6; j += 2) {
-                const int t0 = 6 * hf + j;
-                f4 acc0 = ldg4(W.bqkv + 16 * t0 + 4 * g);
-                f4 acc1 = ldg4(W.bqkv + 16 * (t0 + 1) + 4 * g);
-                gemm_pair_k200(acc0, acc1, wq(t0), wq(t0 + 1), bf, lane);
-                qa[j] = acc0 * a.qscale;
-                qa[j + 1] = acc1 * a.qscale;
+            for (int j = 0; j < 20; ++j) acc[j] = ldg4(W.bqkv[hf] + 16 * j + 4 * g);
+            const float* brow = Xn + (16 * tt + c) * kXS + 4 * g;
+            f4 bb = lds4(brow);
+            SUBT_START();
+#pragma unroll 1
+            for (int kc = 0; kc < kKC; ++kc) {
+                const f4 bn = lds4(brow + 16 * (kc + 1));     // chunk 13 = next row's first columns: finite, unused
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp) {
+                    f4 af[5];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) af[u] = sq.take(u);
+                    mma_group<5>(&acc[5 * grp], af, bb);
+                }
+                bb = bn;
             }
-            {   // Q tile 6 paired with K/V slot 0
-                int pt, nc; float* db;
-                kv_tile(0, pt, db, nc);
-                f4 acc0 = ldg4(W.bqkv + 16 * (6 * hf + 6) + 4 * g);
-                f4 acc1 = ldg4(W.bqkv + 16 * pt + 4 * g);
-                gemm_pair_k200(acc0, acc1, wq(6 * hf + 6), wq(pt), bf, lane);
-                qa[6] = acc0 * a.qscale;
-                if (nc < kXS) *reinterpret_cast<f4*>(db + (16 * tt + c) * kXS + nc) = acc1;
-            }
+            SUBT_ADD(0);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) qa[j] = acc[j] * a.qscale;
             // rows of tile 6 that belong to the other head contribute nothing to this head's q.k
             if (hf == 0) { if (g != 0) qa[6] = zero4(); } else { if (g == 0) qa[0] = zero4(); }
-            for (int s2 = 1; s2 < 13; s2 += 2) {
-                int pt0, pt1, nc0, nc1; float *db0, *db1;
-                kv_tile(s2, pt0, db0, nc0);
-                kv_tile(s2 + 1, pt1, db1, nc1);
-                f4 acc0 = ldg4(W.bqkv + 16 * pt0 + 4 * g);
-                f4 acc1 = ldg4(W.bqkv + 16 * pt1 + 4 * g);
-                gemm_pair_k200(acc0, acc1, wq(pt0), wq(pt1), bf, lane);
-                if (nc0 < kXS) *reinterpret_cast<f4*>(db0 + (16 * tt + c) * kXS + nc0) = acc0;
-                if (nc1 < kXS) *reinterpret_cast<f4*>(db1 + (16 * tt + c) * kXS + nc1) = acc1;
+            float* krow = Kb + (16 * tt + c) * kXS + 4 * g;
+            float* vrow = Vb + (16 * tt + c) * kXS + 4 * g;
+#pragma unroll
+            for (int j = 7; j < 20; ++j) {
+                // hf=0: j 7..13 -> K tile j-7, j 14..19 -> V tile j-14 ; hf=1: j 7..12 -> K tile j, j 13..19 -> V tile j-7
+                const bool isk = hf ? (j < 13) : (j < 14);
+                const int tile = hf ? (j < 13 ? j : j - 7) : (j < 14 ? j - 7 : j - 14);
+                if (16 * tile + 4 * g < kXS) *reinterpret_cast<f4*>((isk ? krow : vrow) + 16 * tile) = acc[j];
             }
+            SUBT_ADD(1);
         }
+        STAMP(5 + 8 * l);
         __syncthreads();
+        STAMP(6 + 8 * l);
 
         // ================= attention for (token tile tt, head hf) =================
         f4 y[kNT];
@@ -396,16 +474,25 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused(const FusedArgs a) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) sa[kt] = zero4();
             // S^T[key][query] = sum_d K[key][d] * Q^T[d][query]
+            {
+                const float* kbase = Kb + c * kXS + 16 * 6 * hf + 4 * g;
+                f4 kf[4], kn[4];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const int col = 16 * (6 * hf + j) + 4 * g;
+                for (int kt = 0; kt < 4; ++kt) kf[kt] = lds4(kbase + 16 * kt * kXS);
 #pragma unroll
-                for (int kt = 0; kt < 4; kt += 2) {
-                    const f4 k0 = lds4(Kb + (16 * kt + c) * kXS + col);
-                    const f4 k1 = lds4(Kb + (16 * (kt + 1) + c) * kXS + col);
-                    mma_chunk2(sa[kt], sa[kt + 1], k0, k1, qa[j]);
+                for (int j = 0; j < 7; ++j) {
+                    if (j + 1 < 7) {
+#pragma unroll
+                        for (int kt = 0; kt < 4; ++kt) kn[kt] = lds4(kbase + 16 * kt * kXS + 16 * (j + 1));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_group<4>(sa, kf, qa[j]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) kf[kt] = kn[kt];
                 }
             }
+            so.open(W.wo[hf], lane);        // out-projection fragments fly during softmax + P.V
             // softmax over keys (rows: 16kt + 4g + r); keys >= T do not exist
             float mx = -INFINITY;
 #pragma unroll
@@ -432,24 +519,52 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused(const FusedArgs a) {
             f4 oa[7];
 #pragma unroll
             for (int j = 0; j < 7; ++j) oa[j] = zero4();
+            {
+                auto load_v = [&](f4 (&va)[7], int kt) {
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                f4 va[7];
+                    for (int j = 0; j < 7; ++j) {
+                        const float* vp = Vb + (16 * kt + 4 * g) * kXS + kHD * hf + 16 * j + c;
+                        va[j].x = vp[0]; va[j].y = vp[kXS]; va[j].z = vp[2 * kXS]; va[j].w = vp[3 * kXS];
+                    }
+                };
+                f4 va[7], vn[7];
+                load_v(va, 0);
 #pragma unroll
-                for (int j = 0; j < 7; ++j) {
-                    const float* vp = Vb + (16 * kt + 4 * g) * kXS + kHD * hf + 16 * j + c;
-                    va[j].x = vp[0]; va[j].y = vp[kXS]; va[j].z = vp[2 * kXS]; va[j].w = vp[3 * kXS];
+                for (int kt = 0; kt < 4; ++kt) {
+                    if (kt + 1 < 4) load_v(vn, kt + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_group<4>(&oa[0], &va[0], sa[kt]);
+                    mma_group<3>(&oa[4], &va[4], sa[kt]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) va[j] = vn[j];
                 }
-                mma_group<4>(&oa[0], &va[0], sa[kt]);
-                mma_group<3>(&oa[4], &va[4], sa[kt]);
             }
-            // out-projection, K-split over heads: y^T[n][q] += Wo[n][100hf + d] * O^T[d][q]
-            const float* wo = W.wo + (size_t)hf * kNT * 7 * kFrag;
+            // out-projection, K-split over heads: y^T[n][q] += Wo[n][100hf + d] * O^T[d][q]; stream order [d-chunk j][n-tile i]
 #pragma unroll
-            for (int j = 0; j < 7; ++j) mma_all_ntiles(y, wo + (size_t)j * kFrag, (size_t)7 * kFrag, oa[j], lane);
+            for (int j = 0; j < 7; ++j) {
+                {
+                    f4 af[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) af[u] = so.take((j * 13 + u) % 7);
+                    mma_group<4>(&y[0], af, oa[j]);
+                    __builtin_amdgcn_sched_barrier(0);       // keep the refills issued HERE (hipcc otherwise sinks them to their use)
+                }
+#pragma unroll
+                for (int i0 = 4; i0 < 13; i0 += 3) {
+                    f4 af[3];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) af[u] = so.take((j * 13 + i0 + u) % 7);
+                    mma_group<3>(&y[i0], af, oa[j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
+        STAMP(7 + 8 * l);
         // exchange partial sums with the partner wave (tt, 1-hf): 52 fragment slots in the (dead) Xn buffer
         // (51 fit; the last one lives in the misc region)
+        FragStream<10> sf;
+        sf.open(W.wffn[hf], lane);          // FFN fragments fly during the exchange + LayerNorm
         {
             auto slot = [&](int tile) -> float* {
                 const int idx = tt * kNT + tile;
@@ -473,37 +588,77 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused(const FusedArgs a) {
             }
         }
 
+        STAMP(8 + 8 * l);
         // ================= LN1 -> Xn (barriers inside also order the exchange reads before the Xn writes) =================
         if (hf == 0) layernorm_to_lds<7>(x, lds, W.ln1g, W.ln1b, tile0, tt, hf, c, g, 1);
         else layernorm_to_lds<6>(x, lds, W.ln1g, W.ln1b, tile0, tt, hf, c, g, 1);
         __syncthreads();
 
-        // ================= FFN: hidden half hf, K-split second GEMM =================
+        STAMP(9 + 8 * l);
+        // ================= FFN: hidden half hf in 5 groups of 5 hidden tiles; second GEMM K-split =================
 #pragma unroll
         for (int i = 0; i < kNT; ++i) y[i] = zero4();
         if (active) {
-            f4 bf[kKC];
-            load_bfrags(bf, Xn, tt, c, g);
-            for (int hh = 0; hh < kHT / 2; ++hh) {
-                const int ht = hf * (kHT / 2) + hh;
-                const float* w1 = W.w1 + (size_t)ht * kKC * kFrag;
-                f4 h0 = ldg4(W.b1 + 16 * ht + 4 * g), h1 = zero4();
+            const float* brow = Xn + (16 * tt + c) * kXS + 4 * g;
+            // the older wave of a SIMD pair (hf=0) wins the pipe arbitration and would idle at the phase barrier:
+            // it takes 6 of the 10 groups, its partner 4 (kFfnGroups0), so both finish together.
+            const int ngrp = hf ? 10 - kFfnGroups0 : kFfnGroups0, ht0 = hf ? 5 * kFfnGroups0 : 0;
+#pragma unroll 1
+            for (int grp = 0; grp < ngrp; ++grp) {
+                f4 h[5];
 #pragma unroll
+                for (int u = 0; u < 5; ++u) h[u] = ldg4(W.b1 + 16 * (ht0 + 5 * grp + u) + 4 * g);
+                // stream slots: 130 fragments per group = 13 x 10, so the ring phase is the same for every group:
+                // chunks 0..11 use slots 0..9 in pairs, chunk 12 uses slots 0..4, the second GEMM starts at slot 5.
+                f4 bb = lds4(brow);
+                SUBT_START();
+#pragma unroll 1
                 for (int kc = 0; kc < 12; kc += 2) {
-                    const f4 a0 = ldg4(w1 + kc * kFrag + lane * 4);
-                    const f4 a1 = ldg4(w1 + (kc + 1) * kFrag + lane * 4);
-                    h0 = mfma(a0.x, bf[kc].x, h0); h1 = mfma(a1.x, bf[kc + 1].x, h1);
-                    h0 = mfma(a0.y, bf[kc].y, h0); h1 = mfma(a1.y, bf[kc + 1].y, h1);
-                    h0 = mfma(a0.z, bf[kc].z, h0); h1 = mfma(a1.z, bf[kc + 1].z, h1);
-                    h0 = mfma(a0.w, bf[kc].w, h0); h1 = mfma(a1.w, bf[kc + 1].w, h1);
+                    const f4 b1 = lds4(brow + 16 * (kc + 1));
+                    const f4 b2 = lds4(brow + 16 * (kc + 2));
+                    f4 af[5], ag[5];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) af[u] = sf.take(u);
+                    mma_group<5>(h, af, bb);
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) ag[u] = sf.take(5 + u);
+                    mma_group<5>(h, ag, b1);
+                    bb = b2;
                 }
-                mma_chunk(h0, ldg4(w1 + 12 * kFrag + lane * 4), bf[12]);
-                f4 h = h0 + h1;
-                h.x = gelu_erf(h.x); h.y = gelu_erf(h.y); h.z = gelu_erf(h.z); h.w = gelu_erf(h.w);   // DyGFormer.py:458
-                const float* w2 = W.w2 + (size_t)ht * kNT * kFrag;
-                mma_all_ntiles(y, w2, (size_t)kFrag, h, lane);
+                {
+                    f4 af[5];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) af[u] = sf.take(u);
+                    mma_group<5>(h, af, bb);
+                }
+                SUBT_ADD(2);
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    h[u].x = gelu_erf(h[u].x); h[u].y = gelu_erf(h[u].y); h[u].z = gelu_erf(h[u].z); h[u].w = gelu_erf(h[u].w);   // DyGFormer.py:458
+                }
+                SUBT_ADD(3);
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    {
+                        f4 af[4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) af[v] = sf.take((5 + u * 13 + v) % 10);
+                        mma_group<4>(&y[0], af, h[u]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int i0 = 4; i0 < 13; i0 += 3) {
+                        f4 af[3];
+#pragma unroll
+                        for (int v = 0; v < 3; ++v) af[v] = sf.take((5 + u * 13 + i0 + v) % 10);
+                        mma_group<3>(&y[i0], af, h[u]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                SUBT_ADD(4);
             }
         }
+        STAMP(10 + 8 * l);
         {   // K and V are dead after attention (every wave passed LN1's barriers): 52 slots from the start of K
             auto slot = [&](int tile) -> float* { return Kb + (size_t)(tt * kNT + tile) * kFrag + lane * 4; };
 #pragma unroll
@@ -527,6 +682,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused(const FusedArgs a) {
         __syncthreads();   // exchange reads of K buffer done before the next layer's K writes / the pooling scratch
     }
 
+    STAMP(3 + 8 * a.NL);
     // ================= per-side mean over tokens + output layer (DyGFormer.py:181-192) =================
     {
         float* pool = Kb;                       // [side][tt][208]
@@ -562,36 +718,54 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused(const FusedArgs a) {
             mean[i] = s / (float)(side ? Td : Ts);
         }
         __syncthreads();
+        // output layer: wave w sums k in [25w, 25w+25) for every output column (coalesced rows of the transposed
+        // weight, 25 independent loads in flight per lane), partial sums meet in LDS.
+        float* part = lds + kLdsV;              // [8 waves][2 sides][Fn]
+        for (int j = lane; j < a.Fn; j += 64) {
+            float ps = 0.f, pd = 0.f;
+#pragma unroll 5
+            for (int k = 25 * wave; k < 25 * wave + 25; ++k) {
+                const float wv = a.outT[(size_t)k * a.Fn + j];
+                ps = fmaf(mean[k], wv, ps);
+                pd = fmaf(mean[kDP + k], wv, pd);
+            }
+            part[(wave * 2 + 0) * a.Fn + j] = ps;
+            part[(wave * 2 + 1) * a.Fn + j] = pd;
+        }
+        __syncthreads();
         for (int i = tid; i < 2 * a.Fn; i += 512) {
             const int side = i / a.Fn, j = i % a.Fn;
-            float acc = 0.f;
-            for (int k = 0; k < kD; ++k) acc = fmaf(mean[side * kDP + k], a.outT[(size_t)k * a.Fn + j], acc);
-            (side ? a.out_dst : a.out_src)[b * a.Fn + j] = acc + a.outb[j];
+            float acc = a.outb[j];
+#pragma unroll
+            for (int wv = 0; wv < 8; ++wv) acc += part[(wv * 2 + side) * a.Fn + j];
+            (side ? a.out_dst : a.out_src)[b * a.Fn + j] = acc;
         }
     }
+    STAMP(4 + 8 * a.NL);
+    SUBT_STORE();
 }
 
 // ================================================================================================
-// packing
+// packing: every weight matrix is cut into 16x16 fragments in MFMA A-operand order and laid out as the
+// linear stream each wave role consumes (FragStream)
 // ================================================================================================
-// dst fragment (slot = chunk_major ? chunk*n_tiles + tile : tile*n_chunks + chunk), lane (c,g), element t:
-//   row = r0 + 16*tile + c   valid iff 0 <= row < rmax          (row of src, ld = src row stride)
-//   col = c0 + 16*chunk + 4g + t   valid iff cmin <= col < cmax
+// fragment slot = tile*ts + chunk*cs ; lane (c,g), element t:
+//   row = r0 + 16*tile + c          valid iff 0 <= row < rmax      (row of src, ld = src row stride)
+//   col = c0 + 16*chunk + 4g + t    valid iff cmin <= col < cmax
 __global__ void k_pack_frag(const float* __restrict__ src, int ld, int n_tiles, int n_chunks, int r0, int rmax, int c0, int cmin,
-                            int cmax, int chunk_major, float* __restrict__ dst) {
+                            int cmax, int ts, int cs, float* __restrict__ dst) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)n_tiles * n_chunks * kFrag;
     if (idx >= total) return;
     const int t = idx & 3, lane = (idx >> 2) & 63;
-    const int64_t slot = idx >> 8;
-    const int tile = chunk_major ? (int)(slot % n_tiles) : (int)(slot / n_chunks);
-    const int chunk = chunk_major ? (int)(slot / n_tiles) : (int)(slot % n_chunks);
+    const int64_t f = idx >> 8;
+    const int tile = (int)(f / n_chunks), chunk = (int)(f % n_chunks);
     const int c = lane & 15, g = lane >> 4;
     const int row = r0 + 16 * tile + c;
     const int col = c0 + 16 * chunk + 4 * g + t;
     float v = 0.f;
     if (row >= 0 && row < rmax && col >= cmin && col < cmax) v = src[(size_t)row * ld + col];
-    dst[idx] = v;
+    dst[((size_t)tile * ts + (size_t)chunk * cs) * kFrag + lane * 4 + t] = v;
 }
 
 __global__ void k_pack_vec(const float* __restrict__ src, int n_valid, int src_off, float* __restrict__ dst, int dst_off, int n_total) {
@@ -600,10 +774,12 @@ __global__ void k_pack_vec(const float* __restrict__ src, int n_valid, int src_o
     dst[dst_off + i] = i < n_valid ? src[src_off + i] : 0.f;
 }
 
+constexpr int kStreamPad = 16;   // fragments of slack after every stream: FragStream prefetches past the end
+
 struct FusedPackLayout {     // float offsets relative to PackedLayout.fused
-    size_t proj[4]; int nchunk[4];
+    size_t proj[5]; int nchunk[4];
     size_t bias_x;
-    struct L { size_t ln0g, ln0b, ln1g, ln1b, wqkv, bqkv, wo, bo, w1, b1, w2, b2; } layer[DYGNN_MAX_LAYERS];
+    struct L { size_t ln0g, ln0b, ln1g, ln1b, wqkv[2], bqkv[2], wo[2], bo, wffn[2], b1, b2; } layer[DYGNN_MAX_LAYERS];
     size_t total;
 };
 
@@ -611,33 +787,37 @@ static FusedPackLayout make_fused_layout(const Dims& d) {
     FusedPackLayout f;
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~size_t(63); return r; };
+    auto take_stream = [&](size_t frags) { return take((frags + kStreamPad) * kFrag); };
     const int K[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * d.C};
-    for (int c = 0; c < 4; ++c) { f.nchunk[c] = (K[c] + 15) / 16; f.proj[c] = take((size_t)4 * f.nchunk[c] * kFrag); }
+    for (int c = 0; c < 4; ++c) f.nchunk[c] = 2 * ((K[c] + 31) / 32);            // even chunk count
+    const int ntl[5] = {4, 4, 1, 3, 4}, chn[5] = {0, 1, 2, 2, 3};
+    for (int i = 0; i < 5; ++i) f.proj[i] = take_stream((size_t)f.nchunk[chn[i]] * ntl[i]);
     f.bias_x = take(kDP);
     for (int l = 0; l < d.NL; ++l) {
         auto& L = f.layer[l];
         L.ln0g = take(kDP); L.ln0b = take(kDP); L.ln1g = take(kDP); L.ln1b = take(kDP);
-        L.wqkv = take((size_t)39 * kKC * kFrag); L.bqkv = take(39 * 16);
-        L.wo = take((size_t)2 * kNT * 7 * kFrag); L.bo = take(kDP);
-        L.w1 = take((size_t)kHT * kKC * kFrag); L.b1 = take(kHid);
-        L.w2 = take((size_t)kHT * kNT * kFrag); L.b2 = take(kDP);
+        for (int h = 0; h < 2; ++h) { L.wqkv[h] = take_stream(20 * kKC); L.bqkv[h] = take(20 * 16); }
+        for (int h = 0; h < 2; ++h) L.wo[h] = take_stream(7 * kNT);
+        L.bo = take(kDP);
+        for (int h = 0; h < 2; ++h) L.wffn[h] = take_stream((size_t)(h ? 10 - kFfnGroups0 : kFfnGroups0) * 130);
+        L.b1 = take(kHid); L.b2 = take(kDP);
     }
     f.total = o;
     return f;
 }
 
 bool fused_supported(const Dims& d) {
-    return d.C == 50 && d.H == 2 && d.Tmax <= kTok && d.Fn % 4 == 0 && d.Fe % 4 == 0 && d.Ft % 4 == 0 &&
+    return d.C == 50 && d.H == 2 && d.Tmax <= kTok && d.Fn <= 512 && d.Fn % 4 == 0 && d.Fe % 4 == 0 && d.Ft % 4 == 0 &&
            (size_t)d.Tmax * d.P * 5 * 4 <= (size_t)kBufFloats * 4 && d.NL <= DYGNN_MAX_LAYERS;
 }
 
 size_t fused_packed_floats(const Dims& d) { return fused_supported(d) ? make_fused_layout(d).total : 0; }
 
 static int pack_frag(const float* src, int ld, int n_tiles, int n_chunks, int r0, int rmax, int c0, int cmin, int cmax,
-                     int chunk_major, float* dst, hipStream_t s) {
+                     int ts, int cs, float* dst, hipStream_t s) {
     const int64_t total = (int64_t)n_tiles * n_chunks * kFrag;
     hipLaunchKernelGGL(k_pack_frag, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, src, ld, n_tiles, n_chunks, r0, rmax, c0,
-                       cmin, cmax, chunk_major, dst);
+                       cmin, cmax, ts, cs, dst);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }
@@ -650,16 +830,19 @@ static int pack_vec(const float* src, int n_valid, int src_off, float* dst, int 
 int pack_fused(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, float* packed, hipStream_t s) {
     const FusedPackLayout f = make_fused_layout(d);
     float* base = packed + pl.fused;
+    DYGNN_HIP(hipMemsetAsync(base, 0, f.total * sizeof(float), s));       // stream slack + padding = finite zeros
     const float* pw[4] = {w->proj_node_w, w->proj_edge_w, w->proj_time_w, w->proj_cooc_w};
     const float* pb[4] = {w->proj_node_b, w->proj_edge_b, w->proj_time_b, w->proj_cooc_b};
     const int K[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * d.C};
-    for (int c = 0; c < 4; ++c) {
-        // model rows 50c .. 50c+49 live in flat tiles (50c)/16 .. +3; src row = flat row - 50c
-        const int t0 = (50 * c) / 16;
-        if (int rc = pack_frag(pw[c], K[c], 4, f.nchunk[c], 16 * t0 - 50 * c, 50, 0, 0, K[c], 0, base + f.proj[c], s)) return rc;
-        if (int rc = pack_vec(pb[c], 50, 0, base + f.bias_x, 50 * c, 50, s)) return rc;
+    // projection streams [chunk][tiles of this half]: model rows 50c..50c+49 live in flat tiles (50c)/16 .. +3,
+    // src row = flat row - 50c.  half 0 owns flat tiles 0..6, half 1 owns 7..12.
+    const int ntl[5] = {4, 4, 1, 3, 4}, chn[5] = {0, 1, 2, 2, 3}, first[5] = {0, 0, 0, 1, 0};
+    for (int i = 0; i < 5; ++i) {
+        const int c = chn[i], t0 = (50 * c) / 16 + first[i];
+        if (int rc = pack_frag(pw[c], K[c], ntl[i], f.nchunk[c], 16 * t0 - 50 * c, 50, 0, 0, K[c], 1, ntl[i], base + f.proj[i], s)) return rc;
     }
-    if (int rc = pack_vec(pb[0], 0, 0, base + f.bias_x, 200, 8, s)) return rc;       // zero the 8 padding rows
+    for (int c = 0; c < 4; ++c)
+        if (int rc = pack_vec(pb[c], 50, 0, base + f.bias_x, 50 * c, 50, s)) return rc;
     for (int l = 0; l < d.NL; ++l) {
         const dygnn_encoder_layer_weights& L = w->layers[l];
         const auto& F = f.layer[l];
@@ -667,18 +850,30 @@ int pack_fused(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weig
         if (int rc = pack_vec(L.norm0_bias, kD, 0, base + F.ln0b, 0, kDP, s)) return rc;
         if (int rc = pack_vec(L.norm1_weight, kD, 0, base + F.ln1g, 0, kDP, s)) return rc;
         if (int rc = pack_vec(L.norm1_bias, kD, 0, base + F.ln1b, 0, kDP, s)) return rc;
-        for (int part = 0; part < 3; ++part) {      // q | k | v row blocks of in_proj
-            if (int rc = pack_frag(L.in_proj_weight + (size_t)part * kD * kD, kD, kNT, kKC, 0, kD, 0, 0, kD, 0,
-                                   base + F.wqkv + (size_t)part * kNT * kKC * kFrag, s)) return rc;
-            if (int rc = pack_vec(L.in_proj_bias, kD, part * kD, base + F.bqkv, part * kDP, kDP, s)) return rc;
+        for (int h = 0; h < 2; ++h) {
+            // QKV stream of half h: [chunk][j], j = 0..19: Q tiles 6h..6h+6, then K / V tiles of the half
+            for (int j = 0; j < 20; ++j) {
+                int part, tile;                   // part: 0 q, 1 k, 2 v row block of in_proj
+                if (j < 7) { part = 0; tile = 6 * h + j; }
+                else if (h == 0) { part = j < 14 ? 1 : 2; tile = j < 14 ? j - 7 : j - 14; }
+                else { part = j < 13 ? 1 : 2; tile = j < 13 ? j : j - 7; }
+                if (int rc = pack_frag(L.in_proj_weight + (size_t)part * kD * kD, kD, 1, kKC, 16 * tile, kD, 0, 0, kD, 0, 20,
+                                       base + F.wqkv[h] + (size_t)j * kFrag, s)) return rc;
+                const int nv = kD - 16 * tile < 16 ? (kD - 16 * tile > 0 ? kD - 16 * tile : 0) : 16;
+                if (int rc = pack_vec(L.in_proj_bias, nv, part * kD + 16 * tile, base + F.bqkv[h], 16 * j, 16, s)) return rc;
+            }
+            // out-projection stream of head h: [d-chunk][n-tile]
+            if (int rc = pack_frag(L.out_proj_weight, kD, kNT, 7, 0, kD, kHD * h, kHD * h, kHD * (h + 1), 1, kNT, base + F.wo[h], s)) return rc;
+            // FFN stream of half h: 5 groups x { W1 [chunk][5 hidden tiles] (65) , W2 [5 hidden chunks][13 n-tiles] (65) }
+            for (int grp = 0; grp < (h ? 10 - kFfnGroups0 : kFfnGroups0); ++grp) {
+                const int ht0 = (h ? 5 * kFfnGroups0 : 0) + 5 * grp;
+                float* gb = base + F.wffn[h] + (size_t)grp * 130 * kFrag;
+                if (int rc = pack_frag(L.ffn0_weight, kD, 5, kKC, 16 * ht0, kHid, 0, 0, kD, 1, 5, gb, s)) return rc;
+                if (int rc = pack_frag(L.ffn1_weight, kHid, kNT, 5, 0, kD, 16 * ht0, 0, kHid, 1, kNT, gb + (size_t)65 * kFrag, s)) return rc;
+            }
         }
-        for (int h = 0; h < 2; ++h)
-            if (int rc = pack_frag(L.out_proj_weight, kD, kNT, 7, 0, kD, kHD * h, kHD * h, kHD * (h + 1), 0,
-                                   base + F.wo + (size_t)h * kNT * 7 * kFrag, s)) return rc;
         if (int rc = pack_vec(L.out_proj_bias, kD, 0, base + F.bo, 0, kDP, s)) return rc;
-        if (int rc = pack_frag(L.ffn0_weight, kD, kHT, kKC, 0, kHid, 0, 0, kD, 0, base + F.w1, s)) return rc;
         if (int rc = pack_vec(L.ffn0_bias, kHid, 0, base + F.b1, 0, kHid, s)) return rc;
-        if (int rc = pack_frag(L.ffn1_weight, kHid, kNT, kHT, 0, kD, 0, 0, kHid, 1, base + F.w2, s)) return rc;
         if (int rc = pack_vec(L.ffn1_bias, kD, 0, base + F.b2, 0, kDP, s)) return rc;
     }
     return DYGNN_OK;
@@ -702,19 +897,23 @@ int forward_fused(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_w
     a.end_pos = reinterpret_cast<const int64_t*>(ws + wl.end_pos);
     a.cd = reinterpret_cast<const CallDims*>(ws + wl.dims);
     a.node_feat = node_feat; a.edge_feat = edge_feat; a.time_w = w->time_w; a.time_b = w->time_b; a.lut = packed + pl.lut;
-    for (int c = 0; c < 4; ++c) { a.proj[c] = base + f.proj[c]; a.nchunk[c] = f.nchunk[c]; }
+    for (int i = 0; i < 5; ++i) a.proj[i] = base + f.proj[i];
+    for (int c = 0; c < 4; ++c) a.nchunk[c] = f.nchunk[c];
     a.bias_x = base + f.bias_x;
     for (int l = 0; l < d.NL; ++l) {
         const auto& F = f.layer[l];
         FusedLayer& L = a.layer[l];
         L.ln0g = base + F.ln0g; L.ln0b = base + F.ln0b; L.ln1g = base + F.ln1g; L.ln1b = base + F.ln1b;
-        L.wqkv = base + F.wqkv; L.bqkv = base + F.bqkv; L.wo = base + F.wo; L.bo = base + F.bo;
-        L.w1 = base + F.w1; L.b1 = base + F.b1; L.w2 = base + F.w2; L.b2 = base + F.b2;
+        for (int h = 0; h < 2; ++h) {
+            L.wqkv[h] = base + F.wqkv[h]; L.bqkv[h] = base + F.bqkv[h]; L.wo[h] = base + F.wo[h]; L.wffn[h] = base + F.wffn[h];
+        }
+        L.bo = base + F.bo; L.b1 = base + F.b1; L.b2 = base + F.b2;
         a.tap_layer[l] = taps ? taps->layer_out[l] : nullptr;
     }
     a.outT = packed + pl.outputT; a.outb = w->output_b;
     a.out_src = out_src; a.out_dst = out_dst;
     a.tap_enc = taps ? taps->encoder_input : nullptr;
+    a.stamps = taps ? reinterpret_cast<unsigned long long*>(taps->phase_cycles) : nullptr;
     a.B = B; a.Fn = d.Fn; a.Fe = d.Fe; a.Ft = d.Ft; a.P = d.P; a.L = d.L; a.NL = d.NL; a.Tmax = d.Tmax;
     a.qscale = (float)sqrt(1.0 / (double)d.hd);
     if (taps && taps->seq_lens) DYGNN_HIP(hipMemcpyAsync(taps->seq_lens, ws + wl.dims + 2 * sizeof(int32_t), 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));

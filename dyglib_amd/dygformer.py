@@ -218,4 +218,7 @@ class DyGFormer(nn.Module):
         s.encoder_input = taps["encoder_input"].data_ptr()
         for l in range(self.num_layers):
             s.layer_out[l] = taps["layer_outputs"][l].data_ptr()
+        if taps.get("want_phase_cycles"):        # only the -DDYGNN_STAMPS diagnostic build writes them
+            taps["phase_cycles"] = torch.zeros((4, 8, 32), dtype=torch.int64, device=dev)
+            s.phase_cycles = taps["phase_cycles"].data_ptr()
         return s

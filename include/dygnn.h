@@ -141,6 +141,8 @@ typedef struct dygnn_dygformer_taps {
     int32_t* seq_lens;                               /* [2]: S_src, S_dst                     */
     float*   encoder_input;
     float*   layer_out[DYGNN_MAX_LAYERS];
+    uint64_t* phase_cycles;                          /* diagnostic builds (-DDYGNN_STAMPS) only:
+                                                        [4 workgroups][8 waves][32] s_memtime stamps */
 } dygnn_dygformer_taps;
 
 /* Kernel-ready copy of the weights (transposed / MFMA-fragment order, co-occurrence LUT).

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of the fused DyGFormer kernel from in-kernel s_memtime stamps.
+Needs the stamps build:  python -m dyglib_amd._build --variant=stamps
+Run:  DYGNN_LIB_VARIANT=stamps python tools/phase_profile.py
+Never quote this build's run time (the stamps perturb it): read the SHARES."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("DYGNN_LIB_VARIANT", "stamps")
+from dyglib_amd import DyGFormer, get_neighbor_sampler, synthetic as syn  # noqa: E402
+
+dev = "cuda:0"
+data, nf, ef = syn.make_bipartite_graph(8227, 1000, 157474, seed=0)
+params = syn.make_dygformer_params(0, patch_size=2)
+sampler = get_neighbor_sampler(data, "recent", seed=1, device=dev)
+model = DyGFormer(nf, ef, sampler, 100, 50, patch_size=2, num_layers=2, num_heads=2, dropout=0.1,
+                  max_input_sequence_length=64, device=dev)
+model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+model = model.to(dev).eval()
+model.impl = 2
+E = data.num_interactions
+sl = slice(E - 200, E)
+src, dst, t = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]
+with torch.no_grad():
+    for _ in range(3):
+        model.compute_src_dst_node_temporal_embeddings(src, dst, t)
+    taps = {"want_phase_cycles": True}
+    model.compute_src_dst_node_temporal_embeddings(src, dst, t, _taps=taps)
+torch.cuda.synchronize()
+st = taps["phase_cycles"].cpu().numpy().astype(np.int64)      # [4 wg][8 waves][32]
+NL = 2
+names = ["zero+windows+counts", "projection", "barrier"]
+for l in range(NL):
+    names += [f"L{l} LN0", f"L{l} QKV", f"L{l} barrier(qkv)", f"L{l} attention+outproj", f"L{l} exchange1",
+              f"L{l} LN1", f"L{l} FFN", f"L{l} exchange2+tap"]
+names += ["pool+output"]
+n = len(names) + 1
+d = np.diff(st[:, :, :n], axis=2).astype(np.float64)          # [4][8][n-1]
+tot = (st[:, :, n - 1] - st[:, :, 0]).astype(np.float64)
+print(f"total cycles per wave: mean {tot.mean():.0f} (min {tot.min():.0f} max {tot.max():.0f})")
+print(f"{'phase':28s} {'hf=0 waves':>12s} {'hf=1 waves':>12s} {'share':>7s}")
+for i, nm in enumerate(names):
+    a, b = d[:, :4, i].mean(), d[:, 4:, i].mean()
+    print(f"{nm:28s} {a:12.0f} {b:12.0f} {100 * d[:, :, i].mean() / tot.mean():6.1f}%")
+
+sub = st[:, :, 24:30].astype(np.float64)
+for i, nm in enumerate(["QKV k-loop (2 layers)", "QKV epilogue", "FFN first GEMM", "FFN GELU", "FFN second GEMM"]):
+    print(f"  sub: {nm:26s} hf0 {sub[:, :4, i].mean():10.0f}  hf1 {sub[:, 4:, i].mean():10.0f}")
