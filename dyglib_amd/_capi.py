@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported first: see module docstring)
 from . import _build
 
 DYGNN_MAX_LAYERS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -78,7 +78,7 @@ SIGNATURES = {
                                        C.c_void_p]),
     "dygnn_dygformer_workspace_bytes": (C.c_size_t, [C.POINTER(DygformerConfig), C.c_int64]),
     "dygnn_dygformer_forward": (C.c_int, [C.POINTER(DygformerConfig), C.POINTER(DygformerWeights), C.c_void_p, C.POINTER(Csr),
-                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(DygformerTaps),
                                           C.c_int32, C.c_void_p]),
     "dygnn_merge_layer_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

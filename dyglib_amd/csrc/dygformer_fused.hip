@@ -154,7 +154,7 @@ struct FusedArgs {
     float *out_src, *out_dst;
     float* tap_enc; float* tap_layer[DYGNN_MAX_LAYERS];
     unsigned long long* stamps;
-    int64_t B;
+    int64_t B, G;               // pairs in the call, pairs per independently padded group
     int Fn, Fe, Ft, P, L, NL, Tmax;
     int nchunk[4];              // per channel, padded to an even count
     float qscale;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused(const FusedArgs a) {
 
     STAMP(0);
     SUBT_DECL;
-    const CallDims cd = *a.cd;
+    const CallDims cd = a.cd[b / a.G];
     const int Ss = cd.S_s, Sd = cd.S_d, Ts = cd.T_s, T = cd.T;
     const int S = Ss + Sd;
 
@@ -880,14 +880,14 @@ int pack_fused(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weig
 }
 
 int window_lengths_device(const Dims& d, const dygnn_csr* csr, const int64_t* src, const int64_t* dst, const double* times,
-                          int64_t B, char* ws, const WorkspaceLayout& wl, hipStream_t s);   // dygformer_generic.hip
+                          int64_t B, int64_t G, char* ws, const WorkspaceLayout& wl, hipStream_t s);   // dygformer_generic.hip
 
 int forward_fused(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, const float* packed,
                   const dygnn_csr* csr, const float* node_feat, const float* edge_feat, const int64_t* src,
-                  const int64_t* dst, const double* times, int64_t B, float* out_src, float* out_dst, char* ws,
+                  const int64_t* dst, const double* times, int64_t B, int64_t G, float* out_src, float* out_dst, char* ws,
                   const WorkspaceLayout& wl, const dygnn_dygformer_taps* taps, hipStream_t s) {
     if (!fused_supported(d)) { set_error("fused kernel: unsupported shape"); return DYGNN_E_UNSUPPORTED; }
-    if (int rc = window_lengths_device(d, csr, src, dst, times, B, ws, wl, s)) return rc;
+    if (int rc = window_lengths_device(d, csr, src, dst, times, B, G, ws, wl, s)) return rc;
     const FusedPackLayout f = make_fused_layout(d);
     const float* base = packed + pl.fused;
     FusedArgs a{};
@@ -914,7 +914,7 @@ int forward_fused(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_w
     a.out_src = out_src; a.out_dst = out_dst;
     a.tap_enc = taps ? taps->encoder_input : nullptr;
     a.stamps = taps ? reinterpret_cast<unsigned long long*>(taps->phase_cycles) : nullptr;
-    a.B = B; a.Fn = d.Fn; a.Fe = d.Fe; a.Ft = d.Ft; a.P = d.P; a.L = d.L; a.NL = d.NL; a.Tmax = d.Tmax;
+    a.B = B; a.G = G; a.Fn = d.Fn; a.Fe = d.Fe; a.Ft = d.Ft; a.P = d.P; a.L = d.L; a.NL = d.NL; a.Tmax = d.Tmax;
     a.qscale = (float)sqrt(1.0 / (double)d.hd);
     if (taps && taps->seq_lens) DYGNN_HIP(hipMemcpyAsync(taps->seq_lens, ws + wl.dims + 2 * sizeof(int32_t), 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     static bool attr_set = false;

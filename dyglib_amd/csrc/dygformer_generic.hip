@@ -56,8 +56,12 @@ __global__ void k_cooc_lut(const float* __restrict__ w0, const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // per-call sizes
 // ------------------------------------------------------------------------------------------------
-__global__ void k_call_dims(CallDims* cd, int P) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+// one entry per group: a call may hold several independent batches ("groups" of G consecutive pairs), each padded to
+// its own S_src / S_dst exactly as if it had been a separate reference call
+__global__ void k_call_dims(CallDims* cds, int P, int64_t ngroups) {
+    const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi < ngroups) {
+        CallDims* cd = cds + gi;
         int Ss = cd->maxw_s + 1, Sd = cd->maxw_d + 1;            // + the target node (DyGFormer.py:223)
         if (Ss % P) Ss += P - Ss % P;                            // :224-225
         if (Sd % P) Sd += P - Sd % P;
@@ -87,8 +91,8 @@ __device__ __forceinline__ int64_t wave_lower_bound2(const double* __restrict__ 
 
 // queries 0..B-1 = src side, B..2B-1 = dst side
 __global__ __launch_bounds__(256) void k_window_lengths2(CsrView2 g, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
-                                                           const double* __restrict__ times, int64_t B, int32_t L,
-                                                           int32_t* __restrict__ hist_len, int64_t* __restrict__ end_pos, CallDims* cd) {
+                                                           const double* __restrict__ times, int64_t B, int64_t G, int32_t L,
+                                                           int32_t* __restrict__ hist_len, int64_t* __restrict__ end_pos, CallDims* cds) {
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (q >= 2 * B) return;
@@ -102,6 +106,7 @@ __global__ __launch_bounds__(256) void k_window_lengths2(CsrView2 g, const int64
         const int32_t len = (int32_t)(i - lo);
         hist_len[q] = len;
         end_pos[q] = i;
+        CallDims* cd = cds + r / G;
         atomicMax(is_dst ? &cd->maxw_d : &cd->maxw_s, len < L - 1 ? len : L - 1);
     }
 }
@@ -123,7 +128,7 @@ struct EmbedArgs {
     const float* projT[4];
     const float* proj_b[4];
     float* X;
-    int64_t B;
+    int64_t B, G;
     int Fn, Fe, Ft, C, D, P, L, Tmax, Smax, lut_rows;
     int stage_floats;   // per-wave staging buffer = P * max(Fn,Fe,Ft,C)
 };
@@ -131,7 +136,7 @@ struct EmbedArgs {
 __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t b = blockIdx.x;
-    const CallDims cd = *a.cd;
+    const CallDims cd = a.cd[b / a.G];
     const int Ss = cd.S_s, Sd = cd.S_d, S = Ss + Sd;
     int32_t* ids = reinterpret_cast<int32_t*>(smem);            // [2*Smax]
     int32_t* eids = ids + 2 * a.Smax;
@@ -212,11 +217,11 @@ __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
 // LayerNorm rows (eps 1e-5, biased variance)   models/DyGFormer.py:452, :458
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ X, float* __restrict__ Y, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, int64_t B, int Tmax, int D, const CallDims* cd) {
+                                                     const float* __restrict__ beta, int64_t B, int Tmax, int D, const CallDims* cd, int64_t G) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * Tmax) return;
-    if ((int)(row % Tmax) >= cd->T) return;
+    if ((int)(row % Tmax) >= cd[(row / Tmax) / G].T) return;
     const float* x = X + row * D;
     float s = 0.f;
     for (int k = lane; k < D; k += kWave) s += x[k];
@@ -232,18 +237,17 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ X, 
 // ------------------------------------------------------------------------------------------------
 template <bool GELU, bool RESIDUAL>
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
-                                                float* __restrict__ Cm, int64_t M, int N, int K, int Tmax, const CallDims* cd) {
+                                                float* __restrict__ Cm, int64_t M, int N, int K, int Tmax, const CallDims* cd, int64_t G) {
     __shared__ float As[16][64 + 1];
     __shared__ float Bs[16][64 + 1];
     const int64_t m0 = (int64_t)blockIdx.x * 64;
     const int n0 = blockIdx.y * 64;
-    const int T = cd->T;
+    auto live = [&](int64_t r) { return r < M && (int)(r % Tmax) < cd[(r / Tmax) / G].T; };
     // skip tiles whose rows are all padding tokens
     {
         bool any = false;
         for (int i = 0; i < 64 && !any; i += 1) {
-            const int64_t r = m0 + i;
-            if (r < M && (int)(r % Tmax) < T) any = true;
+            if (live(m0 + i)) any = true;
         }
         if (!any) return;
     }
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, const
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t r = m0 + ty * 4 + i;
-        if (r >= M || (int)(r % Tmax) >= T) continue;
+        if (!live(r)) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = n0 + tx * 4 + j;
@@ -294,10 +298,10 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, const
 // attention for one (pair, head): softmax(q/sqrt(hd) . k^T) v, no mask   (nn.MultiheadAttention)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ QKV, float* __restrict__ O, int Tmax, int D, int hd,
-                                                     const CallDims* cd) {
+                                                     const CallDims* cd, int64_t G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int T = cd->T;
     const int64_t b = blockIdx.x;
+    const int T = cd[b / G].T;
     const int h = blockIdx.y;
     const int ks = hd + 1;                       // odd row stride -> conflict-free column reads
     float* Ks = reinterpret_cast<float*>(smem);  // [Tmax][hd+1]
@@ -348,11 +352,11 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ QKV
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pool_output(const float* __restrict__ X, const float* __restrict__ WoT, const float* __restrict__ bo,
                                                        float* __restrict__ out_src, float* __restrict__ out_dst, int Tmax, int D, int Fn,
-                                                       const CallDims* cd) {
+                                                       const CallDims* cd, int64_t G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* mean = reinterpret_cast<float*>(smem);      // [2][D]
     const int64_t b = blockIdx.x;
-    const int Ts = cd->T_s, Td = cd->T_d;
+    const int Ts = cd[b / G].T_s, Td = cd[b / G].T_d;
     for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) {
         const int side = i / D, k = i % D;
         const int t0 = side ? Ts : 0, n = side ? Td : Ts;
@@ -405,32 +409,33 @@ int pack_generic(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_we
 
 template <bool GELU, bool RES>
 static int launch_gemm(const float* A, const float* Wt, const float* bias, float* C, int64_t M, int N, int K, int Tmax,
-                       const CallDims* cd, hipStream_t s) {
+                       const CallDims* cd, int64_t G, hipStream_t s) {
     hipLaunchKernelGGL((k_gemm<GELU, RES>), dim3((unsigned)ceil_div(M, 64), (unsigned)ceil_div(N, 64)), dim3(256), 0, s, A, Wt, bias,
-                       C, M, N, K, Tmax, cd);
+                       C, M, N, K, Tmax, cd, G);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }
 
 int window_lengths_device(const Dims& d, const dygnn_csr* csr, const int64_t* src, const int64_t* dst, const double* times,
-                          int64_t B, char* ws, const WorkspaceLayout& wl, hipStream_t s) {
+                          int64_t B, int64_t G, char* ws, const WorkspaceLayout& wl, hipStream_t s) {
     CallDims* cd = reinterpret_cast<CallDims*>(ws + wl.dims);
-    DYGNN_HIP(hipMemsetAsync(cd, 0, sizeof(CallDims), s));
+    const int64_t ngroups = ceil_div(B, G);
+    DYGNN_HIP(hipMemsetAsync(cd, 0, ngroups * sizeof(CallDims), s));
     CsrView2 g{csr->indptr, csr->nbr, csr->eid, csr->ts, csr->num_nodes};
-    hipLaunchKernelGGL(k_window_lengths2, dim3((unsigned)ceil_div(2 * B, 4)), dim3(256), 0, s, g, src, dst, times, B, d.L,
+    hipLaunchKernelGGL(k_window_lengths2, dim3((unsigned)ceil_div(2 * B, 4)), dim3(256), 0, s, g, src, dst, times, B, G, d.L,
                        reinterpret_cast<int32_t*>(ws + wl.hist_len), reinterpret_cast<int64_t*>(ws + wl.end_pos), cd);
     DYGNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_call_dims, dim3(1), dim3(64), 0, s, cd, d.P);
+    hipLaunchKernelGGL(k_call_dims, dim3((unsigned)ceil_div(ngroups, 64)), dim3(64), 0, s, cd, d.P, ngroups);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }
 
 int forward_generic(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, const float* packed,
                     const dygnn_csr* csr, const float* node_feat, const float* edge_feat, const int64_t* src,
-                    const int64_t* dst, const double* times, int64_t B, float* out_src, float* out_dst, char* ws,
+                    const int64_t* dst, const double* times, int64_t B, int64_t G, float* out_src, float* out_dst, char* ws,
                     const WorkspaceLayout& wl, const dygnn_dygformer_taps* taps, hipStream_t s) {
     DYGNN_REQUIRE(d.Tmax <= 128, "generic path supports at most 128 tokens per pair (2*ceil(L/P) = %d)", d.Tmax);
-    if (int rc = window_lengths_device(d, csr, src, dst, times, B, ws, wl, s)) return rc;
+    if (int rc = window_lengths_device(d, csr, src, dst, times, B, G, ws, wl, s)) return rc;
     const CallDims* cd = reinterpret_cast<const CallDims*>(ws + wl.dims);
     float* X = reinterpret_cast<float*>(ws + wl.X);
     float* Xn = reinterpret_cast<float*>(ws + wl.Xn);
@@ -446,7 +451,7 @@ int forward_generic(const Dims& d, const PackedLayout& pl, const dygnn_dygformer
     ea.time_w = w->time_w; ea.time_b = w->time_b; ea.lut = packed + pl.lut;
     const float* pb[4] = {w->proj_node_b, w->proj_edge_b, w->proj_time_b, w->proj_cooc_b};
     for (int c = 0; c < 4; ++c) { ea.projT[c] = packed + pl.projT[c]; ea.proj_b[c] = pb[c]; }
-    ea.X = X; ea.B = B;
+    ea.X = X; ea.B = B; ea.G = G;
     ea.Fn = d.Fn; ea.Fe = d.Fe; ea.Ft = d.Ft; ea.C = d.C; ea.D = d.D; ea.P = d.P; ea.L = d.L; ea.Tmax = d.Tmax; ea.Smax = d.Smax;
     ea.lut_rows = d.lut_rows;
     int fmax = d.Fn > d.Fe ? d.Fn : d.Fe; fmax = fmax > d.Ft ? fmax : d.Ft; fmax = fmax > d.C ? fmax : d.C;
@@ -471,20 +476,20 @@ int forward_generic(const Dims& d, const PackedLayout& pl, const dygnn_dygformer
 
     for (int l = 0; l < d.NL; ++l) {
         const dygnn_encoder_layer_weights& L = w->layers[l];
-        hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, s, X, Xn, L.norm0_weight, L.norm0_bias, B, d.Tmax, d.D, cd);
+        hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, s, X, Xn, L.norm0_weight, L.norm0_bias, B, d.Tmax, d.D, cd, G);
         DYGNN_LAUNCH_CHECK();
-        if (int rc = launch_gemm<false, false>(Xn, packed + pl.inT[l], L.in_proj_bias, QKV, M, 3 * d.D, d.D, d.Tmax, cd, s)) return rc;
-        hipLaunchKernelGGL(k_attention, dim3((unsigned)B, d.H), dim3(256), att_lds, s, QKV, Xn, d.Tmax, d.D, d.hd, cd);
+        if (int rc = launch_gemm<false, false>(Xn, packed + pl.inT[l], L.in_proj_bias, QKV, M, 3 * d.D, d.D, d.Tmax, cd, G, s)) return rc;
+        hipLaunchKernelGGL(k_attention, dim3((unsigned)B, d.H), dim3(256), att_lds, s, QKV, Xn, d.Tmax, d.D, d.hd, cd, G);
         DYGNN_LAUNCH_CHECK();
-        if (int rc = launch_gemm<false, true>(Xn, packed + pl.outT[l], L.out_proj_bias, X, M, d.D, d.D, d.Tmax, cd, s)) return rc;
-        hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, s, X, Xn, L.norm1_weight, L.norm1_bias, B, d.Tmax, d.D, cd);
+        if (int rc = launch_gemm<false, true>(Xn, packed + pl.outT[l], L.out_proj_bias, X, M, d.D, d.D, d.Tmax, cd, G, s)) return rc;
+        hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, s, X, Xn, L.norm1_weight, L.norm1_bias, B, d.Tmax, d.D, cd, G);
         DYGNN_LAUNCH_CHECK();
-        if (int rc = launch_gemm<true, false>(Xn, packed + pl.f0T[l], L.ffn0_bias, Hid, M, 4 * d.D, d.D, d.Tmax, cd, s)) return rc;
-        if (int rc = launch_gemm<false, true>(Hid, packed + pl.f1T[l], L.ffn1_bias, X, M, d.D, 4 * d.D, d.Tmax, cd, s)) return rc;
+        if (int rc = launch_gemm<true, false>(Xn, packed + pl.f0T[l], L.ffn0_bias, Hid, M, 4 * d.D, d.D, d.Tmax, cd, G, s)) return rc;
+        if (int rc = launch_gemm<false, true>(Hid, packed + pl.f1T[l], L.ffn1_bias, X, M, d.D, 4 * d.D, d.Tmax, cd, G, s)) return rc;
         if (taps && taps->layer_out[l]) DYGNN_HIP(hipMemcpyAsync(taps->layer_out[l], X, act_bytes, hipMemcpyDeviceToDevice, s));
     }
     hipLaunchKernelGGL(k_pool_output, dim3((unsigned)B), dim3(256), (size_t)2 * d.D * sizeof(float), s, X, packed + pl.outputT,
-                       w->output_b, out_src, out_dst, d.Tmax, d.D, d.Fn, cd);
+                       w->output_b, out_src, out_dst, d.Tmax, d.D, d.Fn, cd, G);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }

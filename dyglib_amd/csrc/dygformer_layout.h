@@ -72,9 +72,12 @@ inline PackedLayout make_packed_layout(const Dims& d) {
     return p;
 }
 
+// device-visible per-group sizes (workspace.dims)
+struct CallDims { int32_t maxw_s, maxw_d, S_s, S_d, T_s, T_d, T, pad; };
+
 // ---- workspace (byte offsets) -------------------------------------------------------------------
 struct WorkspaceLayout {
-    size_t dims;        // int32[8]: max_window_src, max_window_dst, S_s, S_d, T_s, T_d, T, -
+    size_t dims;        // CallDims[groups]: max_window_src, max_window_dst, S_s, S_d, T_s, T_d, T, -
     size_t hist_len;    // int32[2B]
     size_t end_pos;     // int64[2B]
     size_t X, Xn, QKV, Hid;   // generic path activations, token stride Tmax
@@ -85,7 +88,7 @@ inline WorkspaceLayout make_workspace_layout(const Dims& d, int64_t B) {
     WorkspaceLayout w;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~size_t(255); return r; };
-    w.dims = take(8 * sizeof(int32_t));
+    w.dims = take((size_t)(B > 0 ? B : 1) * sizeof(CallDims));      // one CallDims per group, at most one group per pair
     w.hist_len = take((size_t)2 * B * sizeof(int32_t));
     w.end_pos = take((size_t)2 * B * sizeof(int64_t));
     const size_t rows = (size_t)B * d.Tmax;
@@ -96,8 +99,5 @@ inline WorkspaceLayout make_workspace_layout(const Dims& d, int64_t B) {
     w.total = o;
     return w;
 }
-
-// device-visible per-call sizes (workspace.dims)
-struct CallDims { int32_t maxw_s, maxw_d, S_s, S_d, T_s, T_d, T, pad; };
 
 }  // namespace dygnn

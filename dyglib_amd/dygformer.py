@@ -104,7 +104,8 @@ class DyGFormer(nn.Module):
             self.neighbor_sampler.reset_random_state()
 
     def compute_src_dst_node_temporal_embeddings(self, src_node_ids, dst_node_ids, node_interact_times,
-                                                 _taps: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                                                 _taps: Optional[dict] = None, _group_size: int = 0
+                                                 ) -> Tuple[torch.Tensor, torch.Tensor]:
         """models/DyGFormer.py:68-194.  ndarray (or already-resident device tensor) [B] int64, [B] int64,
         [B] float64 -> two float32 tensors [B, node_feat_dim] on the model's device."""
         if self.training and torch.is_grad_enabled():
@@ -131,11 +132,27 @@ class DyGFormer(nn.Module):
         rc = self._lib.dygnn_dygformer_forward(
             C.byref(self._cfg), C.byref(weights), packed.data_ptr(), csr,
             self.node_raw_features.data_ptr(), self.edge_raw_features.data_ptr(),
-            src.data_ptr(), dst.data_ptr(), tms.data_ptr(), B, out_src.data_ptr(), out_dst.data_ptr(),
+            src.data_ptr(), dst.data_ptr(), tms.data_ptr(), B, int(_group_size), out_src.data_ptr(), out_dst.data_ptr(),
             ws.data_ptr(), ws.numel(), C.byref(taps_struct) if taps_struct is not None else None,
             int(self.impl), _capi.current_stream_ptr())
         _capi.check(rc)
         return out_src, out_dst
+
+    def compute_src_dst_node_temporal_embeddings_many(self, src_node_ids, dst_node_ids, node_interact_times):
+        """Several independent reference calls in ONE launch: inputs are [N, B] (N calls of B pairs each; e.g. the
+        positive and the negative call of a step, or N evaluation batches).  Row i of the result equals
+        compute_src_dst_node_temporal_embeddings(src[i], dst[i], t[i]) bit for bit (every call keeps its own
+        padded lengths), but the N*B pairs form one grid, which keeps all 256 CUs busy instead of B of them.
+        Returns two float32 tensors [N, B, node_feat_dim]."""
+        dev = self._device()
+        src = self._to_dev(src_node_ids, torch.int64, dev)
+        dst = self._to_dev(dst_node_ids, torch.int64, dev)
+        tms = self._to_dev(node_interact_times, torch.float64, dev)
+        if src.dim() != 2 or src.shape != dst.shape or src.shape != tms.shape:
+            raise AssertionError("expected three [N, B] arrays of equal shape")
+        N, B = src.shape
+        a, b = self.compute_src_dst_node_temporal_embeddings(src.reshape(-1), dst.reshape(-1), tms.reshape(-1), _group_size=B)
+        return a.reshape(N, B, -1), b.reshape(N, B, -1)
 
     # ---- plumbing ------------------------------------------------------------------------------
     def _device(self) -> torch.device:

@@ -138,7 +138,7 @@ typedef struct dygnn_dygformer_weights {
 /* Optional stage taps for parity tests (any member may be NULL).  Row-major, token stride
  * T_max = 2*ceil(L/P):  encoder_input / layer_out[l] are [B, T_max, D]. */
 typedef struct dygnn_dygformer_taps {
-    int32_t* seq_lens;                               /* [2]: S_src, S_dst                     */
+    int32_t* seq_lens;                               /* [2]: S_src, S_dst of group 0          */
     float*   encoder_input;
     float*   layer_out[DYGNN_MAX_LAYERS];
     uint64_t* phase_cycles;                          /* diagnostic builds (-DDYGNN_STAMPS) only:
@@ -153,13 +153,18 @@ int dygnn_dygformer_pack(const dygnn_dygformer_config* cfg_host, const dygnn_dyg
 
 size_t dygnn_dygformer_workspace_bytes(const dygnn_dygformer_config* cfg_host, int64_t batch);
 
-/* impl: 0 = auto (fused MFMA kernel when the shape is supported, else generic),
+/* One launch sequence for `batch` (src,dst,t) pairs.  group_size = G splits the pairs into consecutive
+ * groups of G that are padded independently (each group has its own S_src/S_dst, models/DyGFormer.py:219-226):
+ * the result of every group is bit-identical to a separate reference call on that group, so several
+ * reference calls (e.g. the positive and the negative call of a step, evaluate_models_utils.py:126-136, or
+ * several evaluation batches) run as ONE grid that keeps all 256 CUs busy.  G = 0 or G >= batch: one group.
+ * impl: 0 = auto (fused MFMA kernel when the shape is supported, else generic),
  *       1 = generic multi-kernel path (any shape), 2 = fused kernel (error if unsupported). */
 int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg_host, const dygnn_dygformer_weights* w_host,
                             const void* packed, const dygnn_csr* csr_host,
                             const float* node_feat, const float* edge_feat,
                             const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
-                            float* out_src, float* out_dst,
+                            int64_t group_size, float* out_src, float* out_dst,
                             void* workspace, size_t workspace_bytes,
                             const dygnn_dygformer_taps* taps_host, int32_t impl, dygnn_stream_t stream);
 

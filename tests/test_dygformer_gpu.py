@@ -146,3 +146,29 @@ def test_wikipedia_scale_batch_against_oracle():
             gs, gd = model.compute_src_dst_node_temporal_embeddings(src, dst, t)
             close(gs.cpu().numpy(), os_.numpy(), f"impl {impl} src")
             close(gd.cpu().numpy(), od.numpy(), f"impl {impl} dst")
+
+
+def test_many_calls_in_one_launch_match_separate_calls():
+    """group_size: several independent reference calls as ONE grid.  Every group keeps its own padded lengths, so the
+    result must equal the separate calls BIT FOR BIT, including groups whose S_src/S_dst differ."""
+    c = gc.build_case("hub_p4_l48")
+    model, _ = build_model(c)
+    d = c["data"]
+    E = d.num_interactions
+    B = 12
+    # group 0: the first interactions (short histories, small S), group 1/2: late ones (long dst histories)
+    rows = [np.arange(0, B), np.arange(E - 2 * B, E - B), np.arange(E - B, E)]
+    src = np.stack([d.src_node_ids[r] for r in rows])
+    dst = np.stack([d.dst_node_ids[r] for r in rows])
+    t = np.stack([d.node_interact_times[r] for r in rows])
+    for impl in (1, 2):
+        model.impl = impl
+        with torch.no_grad():
+            many_s, many_d = model.compute_src_dst_node_temporal_embeddings_many(src, dst, t)
+            lens = []
+            for i in range(len(rows)):
+                taps = {}
+                s1, d1 = model.compute_src_dst_node_temporal_embeddings(src[i], dst[i], t[i], _taps=taps)
+                lens.append(tuple(taps["seq_lens"].cpu().tolist()))
+                assert torch.equal(many_s[i], s1) and torch.equal(many_d[i], d1), (impl, i)
+        assert len(set(lens)) > 1, lens          # the groups really were padded to different lengths
