@@ -28,6 +28,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from dyglib_amd import distributed as D  # noqa: E402
 from dyglib_amd import synthetic as syn  # noqa: E402
 
 # algorithmic work of one (src,dst,t) pair at S_src = S_dst = 64 (every batch of this
@@ -142,8 +143,7 @@ def main():
             eq = (pos[:, :, None] == negp[:, None, :]).double().mean(dim=(1, 2))
             m = torch.stack([(gt + 0.5 * eq).sum(), (pos.mean(dim=1) - negp.mean(dim=1)).double().sum(),
                              torch.full((), float(nsteps), dtype=torch.float64, device=dev)])
-            if dist is not None:
-                dist.all_reduce(m)
+            D.reduce_metric_sums(m)                              # RCCL all-reduce of 3 float64 when N > 1
             metric_accs[li % len(streams)].add_(m)
 
     def run_steps(first: int, count: int, evs=None):
@@ -223,7 +223,10 @@ def cpu_baseline(params, mparams, node_feat, edge_feat, data, batches, L, P, bud
     nf, ef = torch.from_numpy(node_feat), torch.from_numpy(edge_feat)
     tp = {k: torch.from_numpy(v) for k, v in params.items()}
     mp = {k: torch.from_numpy(v) for k, v in mparams.items()}
-    cores = torch.get_num_threads()
+    # torch's default (every logical CPU of the host, 256 on the GPU box) oversubscribes these small ops and is 6x
+    # slower than 16 threads — the box's CPU share for one GPU and the measured optimum (tools/cpu_threads.py).
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
     src, dst, neg, t = batches[0]
     orc.link_prediction_step(tp, mp, nf, ef, adj, src, dst, neg, t, P, L)        # warm-up
     n, t0 = 0, time.perf_counter()

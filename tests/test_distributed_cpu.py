@@ -1,0 +1,71 @@
+"""N>1 path on CPU: world_size-2 gloo processes run the sharded evaluation loop; the reduced metrics must
+equal the single-process result.  Also pins the device-side AP / AUC against scikit-learn (the reference's
+utils/metrics.py:5-19)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dyglib_amd import distributed as D
+
+
+def fake_step(i: int):
+    """Deterministic per-batch probabilities (stand-in for the GPU forward; quantised so ties occur)."""
+    rs = np.random.RandomState(1000 + i)
+    n = 200 if i % 5 else 37            # a short last-batch-like case
+    pos = np.round(rs.beta(3, 2, n), 2)
+    neg = np.round(rs.beta(2, 3, n), 2)
+    return torch.from_numpy(pos), torch.from_numpy(neg)
+
+
+def test_metrics_match_sklearn():
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    for i in range(12):
+        pos, neg = fake_step(i)
+        y = np.concatenate([np.ones(len(pos)), np.zeros(len(neg))])
+        s = np.concatenate([pos.numpy(), neg.numpy()])
+        assert abs(float(D.binary_auc(pos, neg)) - roc_auc_score(y, s)) < 1e-12
+        assert abs(float(D.average_precision(pos, neg)) - average_precision_score(y, s)) < 1e-12
+
+
+def test_shard_indices_cover_every_batch_once():
+    for n in (0, 1, 7, 237):
+        for w in (1, 2, 3, 8):
+            seen = sorted(i for r in range(w) for i in D.shard_batch_indices(n, r, w))
+            assert seen == list(range(n))
+            assert all(D.owner_of_batch(i, w) == r for r in range(w) for i in D.shard_batch_indices(n, r, w))
+    with pytest.raises(ValueError):
+        D.shard_batch_indices(4, 2, 2)
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, n_batches: int, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out[rank] = D.evaluate_sharded(fake_step, n_batches, rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_batches", [9, 1])      # odd count: ranks own different numbers of batches; 1: an idle rank
+def test_world_size_2_gloo_matches_single_process(n_batches):
+    single = D.evaluate_sharded(fake_step, n_batches, 0, 1)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), n_batches, out), nprocs=2, join=True)
+    assert set(out.keys()) == {0, 1}
+    for r in (0, 1):
+        assert out[r]["num_batches"] == single["num_batches"] == n_batches
+        assert abs(out[r]["average_precision"] - single["average_precision"]) < 1e-12
+        assert abs(out[r]["roc_auc"] - single["roc_auc"]) < 1e-12
