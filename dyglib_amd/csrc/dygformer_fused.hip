@@ -36,7 +36,8 @@ constexpr int kBufFloats = kTok * kXS;                 // 13056 floats = 52224 B
 constexpr int kLdsXn = 0, kLdsK = kBufFloats, kLdsV = 2 * kBufFloats, kLdsMisc = 3 * kBufFloats;
 constexpr int kLdsBytes = 160 * 1024;
 constexpr int kFrag = 256;     // floats per packed 16x16 fragment
-constexpr int kFfnGroups0 = 6; // FFN hidden groups (of 5 tiles) given to half 0; half 1 takes the other 10 - kFfnGroups0
+constexpr int kFfnStageFrags = 26;   // FFN weight stage: 2 hidden tiles x 13 fragments per half
+constexpr int kFfnStages = 26;       // per half: 13 tile pairs x (W1 stage, W2 stage); the last pair holds one tile + padding
 
 __device__ __forceinline__ f4 mfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -87,6 +88,12 @@ __device__ __forceinline__ void mma_all_ntiles(f4 (&y)[13], const float* wfrag, 
 __device__ __forceinline__ f4 ldg4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ f4 lds4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ f4 zero4() { return f4{0.f, 0.f, 0.f, 0.f}; }
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses straight into LDS at (wave-uniform base + lane*16), no VGPRs.
+__device__ __forceinline__ void dma_frag(const float* gsrc_lane, float* lds_dst_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+}
+
 // A wave's weight fragments arrive as ONE linear stream in consumption order (see pack_fused): a ring of
 // R fragments stays in flight, each take() returns the oldest and immediately re-issues that slot R
 // fragments ahead, so the L2 latency of every 1-KiB fragment read hides behind R*4 MFMAs.  Slot indices are
@@ -563,8 +570,6 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused(const FusedArgs a) {
         STAMP(7 + 8 * l);
         // exchange partial sums with the partner wave (tt, 1-hf): 52 fragment slots in the (dead) Xn buffer
         // (51 fit; the last one lives in the misc region)
-        FragStream<10> sf;
-        sf.open(W.wffn[hf], lane);          // FFN fragments fly during the exchange + LayerNorm
         {
             auto slot = [&](int tile) -> float* {
                 const int idx = tt * kNT + tile;
@@ -595,67 +600,112 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused(const FusedArgs a) {
         __syncthreads();
 
         STAMP(9 + 8 * l);
-        // ================= FFN: hidden half hf in 5 groups of 5 hidden tiles; second GEMM K-split =================
+        // ================= FFN: 25 hidden tiles per half, weights staged through LDS by LDS-DMA =================
+        // The four token-tile waves of a half consume the SAME fragments, so every fragment is brought on chip ONCE
+        // (global_load_lds, no VGPRs) into a double-buffered stage in the K/V buffers (dead until the next layer) and
+        // read by its four consumers with conflict-free ds_read_b128.  Stage = 26 fragments per half: W1 rows of two
+        // hidden tiles (A stage) or the W2 columns of those tiles (B stage).  One barrier per stage: it publishes the
+        // stage loaded during the previous one and frees the buffer the next DMA overwrites.
 #pragma unroll
         for (int i = 0; i < kNT; ++i) y[i] = zero4();
-        if (active) {
+        {
+            float* stg = Kb;                                           // [2 buffers][2 halves][26 frags][256]
+            const float* wsrc = W.wffn[hf] + lane * 4;                 // this half's stream, stage-major
+            // this wave's share of stage st: fragments tt, tt+4, ... (7 slots); issue_part(st, f) issues slot f so the
+            // seven DMAs can be spread between the MFMA groups of the running stage instead of delaying its start
+            auto issue_part = [&](int st, int f) {
+                if (4 * f + tt < kFfnStageFrags) {
+                    float* dst = stg + (size_t)((st & 1) * 2 + hf) * kFfnStageFrags * kFrag;
+                    const float* src = wsrc + (size_t)st * kFfnStageFrags * kFrag;
+                    dma_frag(src + (size_t)(4 * f + tt) * kFrag, dst + (size_t)(4 * f + tt) * kFrag);
+                }
+            };
+            auto issue_stage = [&](int st) {
+#pragma unroll
+                for (int f = 0; f < 7; ++f) issue_part(st, f);
+            };
             const float* brow = Xn + (16 * tt + c) * kXS + 4 * g;
-            // the older wave of a SIMD pair (hf=0) wins the pipe arbitration and would idle at the phase barrier:
-            // it takes 6 of the 10 groups, its partner 4 (kFfnGroups0), so both finish together.
-            const int ngrp = hf ? 10 - kFfnGroups0 : kFfnGroups0, ht0 = hf ? 5 * kFfnGroups0 : 0;
+            // FFN1 bias into LDS once per layer: a per-stage global bias load would put a vmcnt(0) (which also waits for
+            // the stage's LDS-DMA) in front of the first MFMA of every stage
+            float* b1s = lds + kLdsMisc + 768;                           // [800]
+            for (int i = tid; i < kHid; i += 512) b1s[i] = W.b1[i];
+            issue_stage(0);
+            __syncthreads();
+            SUBT_START();
 #pragma unroll 1
-            for (int grp = 0; grp < ngrp; ++grp) {
-                f4 h[5];
+            for (int p = 0; p < 13; ++p) {
+                // ---- A stage: h[u]^T = W1[tile] . Xn^T  (+ b1): two tiles x (even, odd k-chunk) accumulators.
+                // Operands of k-chunk pair j+1 are read from LDS while pair j is multiplied (sched_barrier pins it).
+                f4 h[2];
+                if (!active) issue_stage(2 * p + 1);
+                if (active) {
+                    const float* abuf = stg + (size_t)hf * kFfnStageFrags * kFrag + lane * 4;      // buffer 0
+                    f4 he[2], ho[2];
 #pragma unroll
-                for (int u = 0; u < 5; ++u) h[u] = ldg4(W.b1 + 16 * (ht0 + 5 * grp + u) + 4 * g);
-                // stream slots: 130 fragments per group = 13 x 10, so the ring phase is the same for every group:
-                // chunks 0..11 use slots 0..9 in pairs, chunk 12 uses slots 0..4, the second GEMM starts at slot 5.
-                f4 bb = lds4(brow);
-                SUBT_START();
-#pragma unroll 1
-                for (int kc = 0; kc < 12; kc += 2) {
-                    const f4 b1 = lds4(brow + 16 * (kc + 1));
-                    const f4 b2 = lds4(brow + 16 * (kc + 2));
-                    f4 af[5], ag[5];
+                    for (int u = 0; u < 2; ++u) {
+                        const int ht = 25 * hf + 2 * p + u;
+                        he[u] = (2 * p + u < 25) ? lds4(b1s + 16 * ht + 4 * g) : zero4();
+                        ho[u] = zero4();
+                    }
+                    // two operand sets used alternately (static indices after unrolling): no register copies — a v_mov
+                    // of a register an in-flight MFMA has just read stalls the pipe (measured: -12 % in tools/stream_ubench)
+                    f4 sa0[2][2], sa1[2][2], sb0[2], sb1[2];
+                    auto load_a = [&](int set, int kc) {
+                        sb0[set] = lds4(brow + 16 * kc);
+                        sb1[set] = lds4(brow + 16 * (kc + 1));          // kc+1 == 13: next row, finite, unused
 #pragma unroll
-                    for (int u = 0; u < 5; ++u) af[u] = sf.take(u);
-                    mma_group<5>(h, af, bb);
+                        for (int u = 0; u < 2; ++u) {
+                            sa0[set][u] = lds4(abuf + (size_t)(u * 13 + kc) * kFrag);
+                            sa1[set][u] = lds4(abuf + (size_t)(u * 13 + (kc + 1 < kKC ? kc + 1 : kc)) * kFrag);
+                        }
+                    };
+                    load_a(0, 0);
 #pragma unroll
-                    for (int u = 0; u < 5; ++u) ag[u] = sf.take(5 + u);
-                    mma_group<5>(h, ag, b1);
-                    bb = b2;
-                }
-                {
-                    f4 af[5];
-#pragma unroll
-                    for (int u = 0; u < 5; ++u) af[u] = sf.take(u);
-                    mma_group<5>(h, af, bb);
-                }
-                SUBT_ADD(2);
-#pragma unroll
-                for (int u = 0; u < 5; ++u) {
-                    h[u].x = gelu_erf(h[u].x); h[u].y = gelu_erf(h[u].y); h[u].z = gelu_erf(h[u].z); h[u].w = gelu_erf(h[u].w);   // DyGFormer.py:458
-                }
-                SUBT_ADD(3);
-#pragma unroll
-                for (int u = 0; u < 5; ++u) {
-                    {
-                        f4 af[4];
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) af[v] = sf.take((5 + u * 13 + v) % 10);
-                        mma_group<4>(&y[0], af, h[u]);
+                    for (int kc = 0; kc < kKC; kc += 2) {
+                        const int cur = (kc >> 1) & 1;
+                        if (kc + 2 < kKC) load_a(cur ^ 1, kc + 2);
+                        issue_part(2 * p + 1, kc / 2);                  // one DMA per k-chunk pair (bunching them costs 4 %)
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma_group<2>(he, sa0[cur], sb0[cur]);
+                        if (kc + 1 < kKC) mma_group<2>(ho, sa1[cur], sb1[cur]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    h[0] = he[0] + ho[0];
+                    h[1] = he[1] + ho[1];
 #pragma unroll
-                    for (int i0 = 4; i0 < 13; i0 += 3) {
-                        f4 af[3];
+                    for (int u = 0; u < 2; ++u) {
+                        h[u].x = gelu_erf(h[u].x); h[u].y = gelu_erf(h[u].y); h[u].z = gelu_erf(h[u].z); h[u].w = gelu_erf(h[u].w);   // DyGFormer.py:458
+                    }
+                }
+                SUBT_ADD(2);
+                __syncthreads();
+                SUBT_ADD(3);
+                // ---- B stage: y^T += W2[:, tile] . gelu(h[u])^T ; fragment groups (4,3,3,3) x 2 tiles, prefetched one group ahead
+                if (!active && p + 1 < 13) issue_stage(2 * p + 2);
+                if (active) {
+                    const float* bbuf = stg + (size_t)(2 + hf) * kFfnStageFrags * kFrag + lane * 4;  // buffer 1
+                    f4 fs[2][4];                                        // two fragment sets, used alternately
 #pragma unroll
-                        for (int v = 0; v < 3; ++v) af[v] = sf.take((5 + u * 13 + i0 + v) % 10);
-                        mma_group<3>(&y[i0], af, h[u]);
+                    for (int v = 0; v < 4; ++v) fs[0][v] = lds4(bbuf + (size_t)v * kFrag);
+                    // groups: (u, first n-tile, count)
+#pragma unroll
+                    for (int gi = 0; gi < 8; ++gi) {
+                        const int u = gi >> 2, q = gi & 3;
+                        const int i0 = q == 0 ? 0 : 4 + 3 * (q - 1), n = q == 0 ? 4 : 3;
+                        if (gi + 1 < 8) {
+                            const int u2 = (gi + 1) >> 2, q2 = (gi + 1) & 3;
+                            const int j0 = q2 == 0 ? 0 : 4 + 3 * (q2 - 1), n2 = q2 == 0 ? 4 : 3;
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) if (v < n2) fs[(gi + 1) & 1][v] = lds4(bbuf + (size_t)(u2 * 13 + j0 + v) * kFrag);
+                        }
+                        if (p + 1 < 13 && gi < 7) issue_part(2 * p + 2, gi);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (n == 4) mma_group<4>(&y[i0], fs[gi & 1], h[u]); else mma_group<3>(&y[i0], fs[gi & 1], h[u]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 SUBT_ADD(4);
+                __syncthreads();
             }
         }
         STAMP(10 + 8 * l);
@@ -799,7 +849,7 @@ static FusedPackLayout make_fused_layout(const Dims& d) {
         for (int h = 0; h < 2; ++h) { L.wqkv[h] = take_stream(20 * kKC); L.bqkv[h] = take(20 * 16); }
         for (int h = 0; h < 2; ++h) L.wo[h] = take_stream(7 * kNT);
         L.bo = take(kDP);
-        for (int h = 0; h < 2; ++h) L.wffn[h] = take_stream((size_t)(h ? 10 - kFfnGroups0 : kFfnGroups0) * 130);
+        for (int h = 0; h < 2; ++h) L.wffn[h] = take_stream((size_t)(kFfnStages + 1) * kFfnStageFrags);
         L.b1 = take(kHid); L.b2 = take(kDP);
     }
     f.total = o;
@@ -864,12 +914,14 @@ int pack_fused(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weig
             }
             // out-projection stream of head h: [d-chunk][n-tile]
             if (int rc = pack_frag(L.out_proj_weight, kD, kNT, 7, 0, kD, kHD * h, kHD * h, kHD * (h + 1), 1, kNT, base + F.wo[h], s)) return rc;
-            // FFN stream of half h: 5 groups x { W1 [chunk][5 hidden tiles] (65) , W2 [5 hidden chunks][13 n-tiles] (65) }
-            for (int grp = 0; grp < (h ? 10 - kFfnGroups0 : kFfnGroups0); ++grp) {
-                const int ht0 = (h ? 5 * kFfnGroups0 : 0) + 5 * grp;
-                float* gb = base + F.wffn[h] + (size_t)grp * 130 * kFrag;
-                if (int rc = pack_frag(L.ffn0_weight, kD, 5, kKC, 16 * ht0, kHid, 0, 0, kD, 1, 5, gb, s)) return rc;
-                if (int rc = pack_frag(L.ffn1_weight, kHid, kNT, 5, 0, kD, 16 * ht0, 0, kHid, 1, kNT, gb + (size_t)65 * kFrag, s)) return rc;
+            // FFN stream of half h (hidden tiles 25h .. 25h+24): 13 tile pairs x { A stage: W1 [tile u][13 k-chunks],
+            // B stage: W2 [tile u as k-chunk][13 n-tiles] }, every stage padded to 26 fragments (+ one padding stage).
+            for (int p = 0; p < 13; ++p) {
+                const int ht0 = 25 * h + 2 * p, nt = (p < 12) ? 2 : 1;
+                float* sa = base + F.wffn[h] + (size_t)(2 * p) * kFfnStageFrags * kFrag;
+                float* sb = base + F.wffn[h] + (size_t)(2 * p + 1) * kFfnStageFrags * kFrag;
+                if (int rc = pack_frag(L.ffn0_weight, kD, nt, kKC, 16 * ht0, kHid, 0, 0, kD, 13, 1, sa, s)) return rc;
+                if (int rc = pack_frag(L.ffn1_weight, kHid, kNT, nt, 0, kD, 16 * ht0, 0, kHid, 1, 13, sb, s)) return rc;
             }
         }
         if (int rc = pack_vec(L.out_proj_bias, kD, 0, base + F.bo, 0, kDP, s)) return rc;
