@@ -120,6 +120,32 @@ struct FragStream {
     }
 };
 
+// cos(x) for the time encoder (models/modules.py:37).  Arguments reach ~2.7e6 rad (dt * w, w up to 1), where libm cosf
+// takes its ~150-instruction Payne-Hanek path for the whole wave.  Here: t = x/(2*pi) mod 1 from a two-term product
+// (x*INV_HI rounded + its exact fma error + x*INV_LO: 48 bits of 1/2pi, exact integer part up to |x| ~ 5e7), then an
+// even polynomial on [0, 1/4] revolutions.  |error| <= 3.5e-7 for |x| <= 6e7 (checked against float64 in numpy; the
+// same emulation is in tests); larger arguments (only datasets spanning > 1 year of seconds at w ~ 1) use libm.
+__device__ __forceinline__ float cos_time(float x) {
+    if (!(fabsf(x) <= 3.0e7f)) return cosf(x);
+    const float INV_HI = 0.15915493667125702f, INV_LO = 6.4206382432985265e-09f;
+    const float p = x * INV_HI;
+    const float e = fmaf(x, INV_HI, -p);
+    const float q = fmaf(x, INV_LO, e);
+    const float t = (p - rintf(p)) + q;
+    float u = fabsf(t);
+    u = u > 0.5f ? 1.0f - u : u;
+    const bool flip = u > 0.25f;
+    const float v = flip ? 0.5f - u : u;
+    const float z = v * v;
+    float r = fmaf(7.903536371318467f, z, -26.42625678337438f);
+    r = fmaf(r, z, 60.24464137187666f);
+    r = fmaf(r, z, -85.45681720669373f);
+    r = fmaf(r, z, 64.93939402266829f);
+    r = fmaf(r, z, -19.739208802178716f);
+    r = fmaf(r, z, 1.0f);
+    return flip ? -r : r;
+}
+
 // erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7 over the reals), branch-free: one v_rcp, one v_exp and
 // five fma instead of the ~60-instruction two-branch libm erff.  The reference's GELU is the exact-erf form
 // (F.gelu default, models/DyGFormer.py:458); the approximation error enters the output at < 1e-6, two orders
@@ -276,8 +302,8 @@ __device__ __forceinline__ void project_channel(f4 (&x)[7], const float* wstream
 #ifdef DYGNN_STAMPS
 #define STAMP(i)                                                                                   \
     do {                                                                                           \
-        if (a.stamps != nullptr && lane == 0 && blockIdx.x < 4)                                    \
-            a.stamps[((size_t)blockIdx.x * 8 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime();   \
+        if (a.stamps != nullptr && lane == 0 && blockIdx.x + 4 >= gridDim.x)                       \
+            a.stamps[((size_t)(blockIdx.x + 4 - gridDim.x) * 8 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime();   \
     } while (0)
 #define TICK() __builtin_amdgcn_s_memtime()
 #define SUBT_DECL unsigned long long subt[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tk0 = 0
@@ -285,8 +311,8 @@ __device__ __forceinline__ void project_channel(f4 (&x)[7], const float* wstream
 #define SUBT_ADD(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = TICK(); subt[i] += t_ - tk0; tk0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define SUBT_STORE()                                                                               \
     do {                                                                                           \
-        if (a.stamps != nullptr && lane == 0 && blockIdx.x < 4)                                    \
-            for (int i_ = 0; i_ < 6; ++i_) a.stamps[((size_t)blockIdx.x * 8 + wave) * 32 + 24 + i_] = subt[i_]; \
+        if (a.stamps != nullptr && lane == 0 && blockIdx.x + 4 >= gridDim.x)                       \
+            for (int i_ = 0; i_ < 6; ++i_) a.stamps[((size_t)(blockIdx.x + 4 - gridDim.x) * 8 + wave) * 32 + 24 + i_] = subt[i_]; \
     } while (0)
 #else
 #define STAMP(i) do { } while (0)
@@ -379,8 +405,8 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused(const FusedArgs a) {
             const float dt = dts[pos0 + pp];
             const f4 w = ldg4(a.time_w + f), bb = ldg4(a.time_b + f);
             f4 r;
-            r.x = cosf(fmaf(dt, w.x, bb.x)); r.y = cosf(fmaf(dt, w.y, bb.y));
-            r.z = cosf(fmaf(dt, w.z, bb.z)); r.w = cosf(fmaf(dt, w.w, bb.w));
+            r.x = cos_time(fmaf(dt, w.x, bb.x)); r.y = cos_time(fmaf(dt, w.y, bb.y));
+            r.z = cos_time(fmaf(dt, w.z, bb.z)); r.w = cos_time(fmaf(dt, w.w, bb.w));
             return r;
         };
         auto coocf = [&](int kc) -> f4 {
