@@ -184,6 +184,17 @@ def main():
     fpp = flops_per_pair(L, L, P)
     flop_per_launch = fpp * B * 2 * steps_per_launch
     achieved_tflops = flop_per_launch / (launch_ms * 1e-3) / 1e12
+    # HBM traffic of the fused kernel from the committed PMC passes (profiles/*_traffic.json, measured with
+    # tools/pmc_profile.sh on this command); null when the launch shape differs from the profiled one
+    traffic = None
+    try:
+        import glob
+        tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))[-1]
+        tj = json.load(open(tf))
+        if args.workload == "wikipedia" and args.impl in (0, 2):
+            traffic = tj["hbm_bytes_per_pair"] * 2 * steps_per_launch * B
+    except Exception:
+        traffic = None
     acc = sum(a.cpu().numpy() for a in metric_accs)
 
     out = {
@@ -199,7 +210,7 @@ def main():
                    "impl": {0: "auto", 1: "generic", 2: "fused"}[args.impl], "streams": len(streams),
                    "steps_per_launch": F},
         "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                      "kernel": "k_dygformer_fused (+ the 3 tiny window-search launches in front of it)",
                      "flop_per_launch": flop_per_launch, "ms_per_launch": round(launch_ms, 4),
                      "pairs_per_launch": 2 * steps_per_launch * B},
