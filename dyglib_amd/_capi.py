@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported first: see module docstring)
 from . import _build
 
 DYGNN_MAX_LAYERS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -52,6 +52,18 @@ class DygformerWeights(C.Structure):
                 + [("output_w", C.c_void_p), ("output_b", C.c_void_p)])
 
 
+class TgatConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("node_feat_dim", "edge_feat_dim", "time_feat_dim", "num_layers", "num_heads", "num_neighbors")]
+
+
+class TgatLayerWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("query_w", "key_w", "value_w", "ln_w", "ln_b", "res_w", "res_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class TgatWeights(C.Structure):
+    _fields_ = [("time_w", C.c_void_p), ("time_b", C.c_void_p), ("layers", TgatLayerWeights * DYGNN_MAX_LAYERS)]
+
+
 class DygformerTaps(C.Structure):
     _fields_ = [("seq_lens", C.c_void_p), ("encoder_input", C.c_void_p), ("layer_out", C.c_void_p * DYGNN_MAX_LAYERS),
                 ("phase_cycles", C.c_void_p)]
@@ -81,6 +93,9 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(DygformerTaps),
                                           C.c_int32, C.c_void_p]),
+    "dygnn_tgat_workspace_bytes": (C.c_size_t, [C.POINTER(TgatConfig), C.c_int64]),
+    "dygnn_tgat_forward": (C.c_int, [C.POINTER(TgatConfig), C.POINTER(TgatWeights), C.POINTER(Csr), C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dygnn_merge_layer_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

@@ -1,0 +1,363 @@
+// TGAT forward (BASELINE config 3; reference models/TGAT.py:48-136 + MultiHeadAttention models/modules.py:99-206 +
+// MergeLayer models/modules.py:42-68), eval mode.
+//
+// The reference recurses per node set: layer-l embeddings of a set need layer-(l-1) embeddings of the set itself and of
+// its k most recent neighbours.  Here the recursion is unrolled top-down into level sets (level L = the 2B query nodes,
+// level l-1 = [level-l nodes ; their k neighbours]; neighbour times are the float32 values the sampler returns,
+// models/TGAT.py:107-110) and evaluated bottom-up, one batched pass per layer:
+//   sample_recent -> build [h_nbr | edge | time] rows -> K/V projection (fp32-MFMA GEMM) -> masked attention over the k
+//   keys -> residual_fc + residual + LayerNorm -> MergeLayer (two GEMMs).
+// This round's version keeps the per-layer activations in HBM (correctness + first measurement); fusing the gather with
+// the K/V GEMM is the next step.
+#include "common.h"
+
+namespace dygnn {
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ f4 tmfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// sampler kernel shared with sampler.hip (one wave per query, 64-ary search)
+__device__ __forceinline__ int64_t wave_lower_bound3(const double* __restrict__ ts, int64_t lo, int64_t hi, double t, int lane) {
+    while (hi - lo > kWave) {
+        const int64_t step = (hi - lo + kWave - 1) / kWave;
+        const int64_t p = lo + (int64_t)lane * step;
+        const bool pred = (p < hi) && (ts[p] < t);
+        const int c = __popcll(__ballot(pred));
+        if (c == 0) return lo;
+        const int64_t nlo = lo + (int64_t)(c - 1) * step + 1;
+        const int64_t nhi = lo + (int64_t)c * step;
+        hi = nhi < hi ? nhi : hi;
+        lo = nlo;
+    }
+    const int64_t p = lo + lane;
+    const bool pred = (p < hi) && (ts[p] < t);
+    return lo + __popcll(__ballot(pred));
+}
+
+// level expansion: for the n nodes of a level (ids/times), sample the k most recent neighbours (utils/utils.py:200-209)
+// and append them to the next-lower level: lower = [this level ; neighbours (row-major n x k)].
+// nbr ids / edge ids int32, times float64 holding float32-rounded values (models/TGAT.py:107-110).
+__global__ __launch_bounds__(256) void k_tgat_expand(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cnbr,
+                                                       const int32_t* __restrict__ ceid, const double* __restrict__ cts, int64_t num_nodes,
+                                                       const int32_t* __restrict__ ids, const double* __restrict__ times, int64_t n, int k,
+                                                       int32_t* __restrict__ lower_ids, double* __restrict__ lower_times,
+                                                       int32_t* __restrict__ nbr_eid, float* __restrict__ nbr_dt) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= n) return;
+    int64_t node = ids[q];
+    if (node < 0 || node >= num_nodes) node = 0;
+    const double t = times[q];
+    const int64_t lo = indptr[node], hi = indptr[node + 1];
+    const int64_t i = wave_lower_bound3(cts, lo, hi, t, lane);
+    const int64_t len = i - lo;
+    const int m = (int)(len < k ? len : k), pad = k - m;
+    if (lane == 0) { lower_ids[q] = (int32_t)node; lower_times[q] = t; }
+    for (int j = lane; j < k; j += kWave) {
+        int32_t nb = 0, e = 0;
+        float tn = 0.f;
+        if (j >= pad) {
+            const int64_t p = i - m + (j - pad);
+            nb = cnbr[p]; e = ceid[p]; tn = (float)cts[p];              // float32 on store, utils/utils.py:167
+        }
+        lower_ids[n + q * k + j] = nb;
+        lower_times[n + q * k + j] = (double)tn;                        // hop-(l+1) queries use the float32 time
+        nbr_eid[q * k + j] = e;
+        nbr_dt[q * k + j] = (float)(t - (double)tn);                    // models/TGAT.py:116-119: f64 - f32 -> f64 -> .float()
+    }
+}
+
+// rows of the K/V input [n*k][Fn+Fe+Ft] = [h(neighbour) | edge feature | cos(w dt + b)] and of the query input
+// [n][Fn+Ft] = [h(self) | cos(b)]   (models/modules.py:150-157; the query's time feature is the encoding of dt = 0,
+// models/TGAT.py:84)
+__global__ __launch_bounds__(256) void k_tgat_inputs(const float* __restrict__ h_lower, const float* __restrict__ node_feat,
+                                                       const float* __restrict__ edge_feat, const int32_t* __restrict__ lower_ids,
+                                                       const int32_t* __restrict__ nbr_eid, const float* __restrict__ nbr_dt,
+                                                       const float* __restrict__ tw, const float* __restrict__ tb, int64_t n, int k, int Fn, int Fe,
+                                                       int Ft, float* __restrict__ kv_in, float* __restrict__ q_in) {
+    // row r in [0, n*k): neighbour (i = r / k, j = r % k) = lower-level entry n + r ; rows n*k .. n*k+n-1: the query rows
+    const int64_t r = blockIdx.x;
+    const int Kkv = Fn + Fe + Ft, Kq = Fn + Ft;
+    if (r < n * k) {
+        const int64_t le = n + r;
+        const float* hsrc = h_lower ? h_lower + le * Fn : node_feat + (size_t)lower_ids[le] * Fn;   // layer 1: raw features
+        const float* esrc = edge_feat + (size_t)nbr_eid[r] * Fe;
+        const float dt = nbr_dt[r];
+        float* o = kv_in + r * Kkv;
+        for (int f = threadIdx.x; f < Kkv; f += blockDim.x) {
+            float v;
+            if (f < Fn) v = hsrc[f];
+            else if (f < Fn + Fe) v = esrc[f - Fn];
+            else v = cosf(fmaf(dt, tw[f - Fn - Fe], tb[f - Fn - Fe]));
+            o[f] = v;
+        }
+    } else {
+        const int64_t i = r - n * k;
+        const float* hsrc = h_lower ? h_lower + i * Fn : node_feat + (size_t)lower_ids[i] * Fn;
+        float* o = q_in + i * Kq;
+        for (int f = threadIdx.x; f < Kq; f += blockDim.x) o[f] = f < Fn ? hsrc[f] : cosf(fmaf(0.0f, tw[f - Fn], tb[f - Fn]));
+    }
+}
+
+// C[M][N] = act(A[M][K] . W[N][K]^T + bias): fp32 MFMA, operands straight from global memory (both are K-contiguous, so
+// lane (c,g) of a 16x16x4 fragment reads the float4 at [row c][k0 + 4g]); a wave computes a 64 x 64 block (4x4 tiles).
+// Transposed product: accumulator tile = C^T[n = 4g+r][m = c]  ->  float4 store at C[m][n0 + 4g].
+template <bool RELU>
+__global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+                                                   float* __restrict__ C, int64_t M, int N, int K, int ldc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    const int n0 = blockIdx.y * 64;
+    if (m0 >= M) return;
+    f4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const int kk = k0 + 4 * g;
+        f4 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + 16 * i + c;
+            a[i] = (n < N && kk < K) ? *reinterpret_cast<const f4*>(W + (size_t)n * K + kk) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t m = m0 + 16 * j + c;
+            b[j] = (m < M && kk < K) ? *reinterpret_cast<const f4*>(A + (size_t)m * K + kk) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = tmfma(a[i].x, b[j].x, acc[i][j]);
+                acc[i][j] = tmfma(a[i].y, b[j].y, acc[i][j]);
+                acc[i][j] = tmfma(a[i].z, b[j].z, acc[i][j]);
+                acc[i][j] = tmfma(a[i].w, b[j].w, acc[i][j]);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + 16 * i + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t m = m0 + 16 * j + c;
+            if (m >= M) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (n + r < N) {
+                    float v = acc[i][j][r] + (bias ? bias[n + r] : 0.f);
+                    if (RELU) v = fmaxf(v, 0.f);
+                    C[(size_t)m * ldc + n + r] = v;
+                }
+            }
+        }
+    }
+}
+
+// one wave per node: scores over the k keys per head, * head_dim^-0.5, masked_fill(id == 0, -1e10), softmax, weighted
+// sum of V (models/modules.py:168-191).  q [n][H*hd], kv [n*k][2*H*hd] (K then V), out [n][H*hd]
+__global__ __launch_bounds__(256) void k_tgat_attention(const float* __restrict__ q, const float* __restrict__ kv, const int32_t* __restrict__ lower_ids,
+                                                          int64_t n, int k, int H, int hd, float scale, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= n) return;
+    float* pw = reinterpret_cast<float*>(smem) + wave * H * k;       // [H][k] probabilities
+    const int D = H * hd;
+    for (int hj = lane; hj < H * k; hj += kWave) {
+        const int h = hj / k, j = hj % k;
+        const float* qv = q + i * D + h * hd;
+        const float* kvr = kv + (size_t)(i * k + j) * 2 * D + h * hd;
+        float s = 0.f;
+        for (int d = 0; d < hd; ++d) s = fmaf(qv[d], kvr[d], s);
+        s *= scale;                                                   // modules.py:173
+        if (lower_ids[n + i * k + j] == 0) s = -1e10f;                // modules.py:176-184
+        pw[hj] = s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int h = 0; h < H; ++h) {
+        float mx = -INFINITY;
+        for (int j = 0; j < k; ++j) mx = fmaxf(mx, pw[h * k + j]);
+        float sum = 0.f;
+        for (int j = 0; j < k; ++j) sum += expf(pw[h * k + j] - mx);
+        const float inv = 1.0f / sum;
+        for (int d = lane; d < hd; d += kWave) {
+            float acc = 0.f;
+            for (int j = 0; j < k; ++j)
+                acc = fmaf(expf(pw[h * k + j] - mx) * inv, kv[(size_t)(i * k + j) * 2 * D + D + h * hd + d], acc);
+            out[i * D + h * hd + d] = acc;
+        }
+    }
+}
+
+// y = LayerNorm(fc_out + residual) (models/modules.py:196-199), written into the first Dq columns of the MergeLayer input
+// row [Dq + Fn]; the raw node features fill the rest (models/TGAT.py:134, models/modules.py:64)
+__global__ __launch_bounds__(256) void k_tgat_post(const float* __restrict__ fc_out, const float* __restrict__ q_in, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ node_feat,
+                                                     const int32_t* __restrict__ lower_ids, int64_t n, int Dq, int Fn, float* __restrict__ merge_in) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    float s = 0.f;
+    for (int f = lane; f < Dq; f += kWave) s += fc_out[i * Dq + f] + q_in[i * Dq + f];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)Dq;
+    float v = 0.f;
+    for (int f = lane; f < Dq; f += kWave) { const float d = fc_out[i * Dq + f] + q_in[i * Dq + f] - mean; v = fmaf(d, d, v); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const float rstd = 1.0f / sqrtf(v / (float)Dq + 1e-5f);
+    float* o = merge_in + i * (Dq + Fn);
+    for (int f = lane; f < Dq; f += kWave) o[f] = (fc_out[i * Dq + f] + q_in[i * Dq + f] - mean) * rstd * gamma[f] + beta[f];
+    const float* raw = node_feat + (size_t)lower_ids[i] * Fn;
+    for (int f = lane; f < Fn; f += kWave) o[Dq + f] = raw[f];
+}
+
+__global__ void k_cast_ids(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const double* __restrict__ t, int64_t B,
+                           int32_t* __restrict__ ids, double* __restrict__ times) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * B) return;
+    ids[i] = (int32_t)(i < B ? src[i] : dst[i - B]);
+    times[i] = t[i < B ? i : i - B];
+}
+
+__global__ void k_split_out(const float* __restrict__ h, int64_t B, int Fn, float* __restrict__ out_src, float* __restrict__ out_dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * B * Fn) return;
+    const int64_t r = i / Fn;
+    (r < B ? out_src : out_dst)[(r < B ? r : r - B) * Fn + i % Fn] = h[i];
+}
+
+struct TgatPlan {
+    int L, k, Fn, Fe, Ft, H, hd, Dq, Dkv;
+    int64_t n[DYGNN_MAX_LAYERS + 1];       // level sizes: n[L] = 2B, n[l-1] = n[l] * (1 + k)
+    // byte offsets
+    size_t ids[DYGNN_MAX_LAYERS + 1], times[DYGNN_MAX_LAYERS + 1], eid[DYGNN_MAX_LAYERS + 1], dt[DYGNN_MAX_LAYERS + 1], h[DYGNN_MAX_LAYERS + 1];
+    size_t kv_in, q_in, kv, q, att, fc, merge_in, hid, total;
+};
+
+static TgatPlan make_tgat_plan(const dygnn_tgat_config& c, int64_t B) {
+    TgatPlan p{};
+    p.L = c.num_layers; p.k = c.num_neighbors; p.Fn = c.node_feat_dim; p.Fe = c.edge_feat_dim; p.Ft = c.time_feat_dim; p.H = c.num_heads;
+    p.Dq = p.Fn + p.Ft; p.Dkv = p.Fn + p.Fe + p.Ft; p.hd = p.H > 0 ? p.Dq / p.H : 0;
+    p.n[p.L] = 2 * B;
+    for (int l = p.L; l >= 1; --l) p.n[l - 1] = p.n[l] * (1 + p.k);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~size_t(255); return r; };
+    for (int l = 0; l <= p.L; ++l) {
+        p.ids[l] = take(p.n[l] * sizeof(int32_t));
+        p.times[l] = take(p.n[l] * sizeof(double));
+        p.h[l] = l >= 1 ? take((size_t)p.n[l] * p.Fn * sizeof(float)) : 0;
+        p.eid[l] = l >= 1 ? take((size_t)p.n[l] * p.k * sizeof(int32_t)) : 0;
+        p.dt[l] = l >= 1 ? take((size_t)p.n[l] * p.k * sizeof(float)) : 0;
+    }
+    const int64_t nmax = p.L >= 1 ? p.n[1] : 0;                        // the largest computed level
+    p.kv_in = take((size_t)nmax * p.k * p.Dkv * sizeof(float));
+    p.q_in = take((size_t)nmax * p.Dq * sizeof(float));
+    p.kv = take((size_t)nmax * p.k * 2 * p.Dq * sizeof(float));
+    p.q = take((size_t)nmax * p.Dq * sizeof(float));
+    p.att = take((size_t)nmax * p.Dq * sizeof(float));
+    p.fc = take((size_t)nmax * p.Dq * sizeof(float));
+    p.merge_in = take((size_t)nmax * (p.Dq + p.Fn) * sizeof(float));
+    p.hid = take((size_t)nmax * p.Fn * sizeof(float));
+    p.total = o;
+    return p;
+}
+
+static int check_tgat(const dygnn_tgat_config* c) {
+    DYGNN_REQUIRE(c != nullptr, "tgat: config is NULL");
+    DYGNN_REQUIRE(c->node_feat_dim > 0 && c->edge_feat_dim > 0 && c->time_feat_dim > 0, "tgat: feature dims must be positive");
+    DYGNN_REQUIRE(c->node_feat_dim % 4 == 0 && c->edge_feat_dim % 4 == 0 && c->time_feat_dim % 4 == 0, "tgat: feature dims must be multiples of 4");
+    DYGNN_REQUIRE(c->num_layers >= 1 && c->num_layers <= 3, "tgat: num_layers must be in [1,3]");
+    // models/modules.py:120
+    DYGNN_REQUIRE(c->num_heads >= 1 && (c->node_feat_dim + c->time_feat_dim) % c->num_heads == 0,
+                  "The sum of node_feat_dim and time_feat_dim should be divided by num_heads!");
+    // utils/utils.py:157
+    DYGNN_REQUIRE(c->num_neighbors > 0, "Number of sampled neighbors for each node should be greater than 0!");
+    DYGNN_REQUIRE(c->num_neighbors <= 64, "tgat: num_neighbors > 64 not supported");
+    return DYGNN_OK;
+}
+
+template <bool RELU>
+static int gemm_nt(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, int ldc, hipStream_t s) {
+    if (M == 0) return DYGNN_OK;
+    hipLaunchKernelGGL((k_gemm_nt<RELU>), dim3((unsigned)ceil_div(M, 256), (unsigned)ceil_div(N, 64)), dim3(256), 0, s, A, W, bias, C, M, N, K, ldc);
+    DYGNN_LAUNCH_CHECK();
+    return DYGNN_OK;
+}
+
+}  // namespace dygnn
+
+using namespace dygnn;
+
+extern "C" size_t dygnn_tgat_workspace_bytes(const dygnn_tgat_config* cfg, int64_t batch) {
+    if (check_tgat(cfg) != DYGNN_OK || batch < 0) return 0;
+    return make_tgat_plan(*cfg, batch).total;
+}
+
+extern "C" int dygnn_tgat_forward(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_csr* csr, const float* node_feat,
+                                  const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
+                                  float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
+    if (int rc = check_tgat(cfg)) return rc;
+    DYGNN_REQUIRE(w && w->time_w && w->time_b, "tgat: null weights");
+    DYGNN_REQUIRE(csr && csr->indptr && csr->num_nodes >= 1, "tgat: bad csr");
+    DYGNN_REQUIRE(batch >= 0 && node_feat && edge_feat, "tgat: bad arguments");
+    if (batch == 0) return DYGNN_OK;
+    DYGNN_REQUIRE(src && dst && times && out_src && out_dst && workspace, "tgat: null pointer");
+    const TgatPlan p = make_tgat_plan(*cfg, batch);
+    if (workspace_bytes < p.total) {
+        set_error("tgat: workspace too small (%zu < %zu bytes)", workspace_bytes, p.total);
+        return DYGNN_E_WORKSPACE;
+    }
+    for (int l = 0; l < p.L; ++l) {
+        const dygnn_tgat_layer_weights& Lw = w->layers[l];
+        DYGNN_REQUIRE(Lw.query_w && Lw.key_w && Lw.value_w && Lw.ln_w && Lw.ln_b && Lw.res_w && Lw.res_b && Lw.fc1_w && Lw.fc1_b && Lw.fc2_w && Lw.fc2_b,
+                      "tgat: null layer weights (layer %d)", l);
+    }
+    hipStream_t s = as_stream(stream);
+    char* ws = static_cast<char*>(workspace);
+    auto I32 = [&](size_t off) { return reinterpret_cast<int32_t*>(ws + off); };
+    auto F64 = [&](size_t off) { return reinterpret_cast<double*>(ws + off); };
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+
+    // level L = [src ; dst]
+    hipLaunchKernelGGL(k_cast_ids, dim3((unsigned)ceil_div(2 * batch, 256)), dim3(256), 0, s, src, dst, times, batch, I32(p.ids[p.L]), F64(p.times[p.L]));
+    DYGNN_LAUNCH_CHECK();
+    // top-down: sample neighbours of every level, building the level below
+    for (int l = p.L; l >= 1; --l) {
+        hipLaunchKernelGGL(k_tgat_expand, dim3((unsigned)ceil_div(p.n[l], 4)), dim3(256), 0, s, csr->indptr, csr->nbr, csr->eid, csr->ts, csr->num_nodes,
+                           I32(p.ids[l]), F64(p.times[l]), p.n[l], p.k, I32(p.ids[l - 1]), F64(p.times[l - 1]), I32(p.eid[l]), F32(p.dt[l]));
+        DYGNN_LAUNCH_CHECK();
+    }
+    // bottom-up: layer l turns level-(l-1) embeddings (raw features for l = 1) into level-l embeddings
+    const float scale = (float)pow((double)p.hd, -0.5);
+    for (int l = 1; l <= p.L; ++l) {
+        const dygnn_tgat_layer_weights& Lw = w->layers[l - 1];
+        const int64_t n = p.n[l];
+        const float* h_lower = l >= 2 ? F32(p.h[l - 1]) : nullptr;
+        hipLaunchKernelGGL(k_tgat_inputs, dim3((unsigned)(n * p.k + n)), dim3(256), 0, s, h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]),
+                           F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, F32(p.kv_in), F32(p.q_in));
+        DYGNN_LAUNCH_CHECK();
+        // K and V projections write the two halves of one [n*k][2*Dq] buffer (bias-free, modules.py:126-128)
+        if (int rc = gemm_nt<false>(F32(p.kv_in), Lw.key_w, nullptr, F32(p.kv), n * p.k, p.Dq, p.Dkv, 2 * p.Dq, s)) return rc;
+        if (int rc = gemm_nt<false>(F32(p.kv_in), Lw.value_w, nullptr, F32(p.kv) + p.Dq, n * p.k, p.Dq, p.Dkv, 2 * p.Dq, s)) return rc;
+        if (int rc = gemm_nt<false>(F32(p.q_in), Lw.query_w, nullptr, F32(p.q), n, p.Dq, p.Dq, p.Dq, s)) return rc;
+        hipLaunchKernelGGL(k_tgat_attention, dim3((unsigned)ceil_div(n, 4)), dim3(256), (size_t)4 * p.H * p.k * sizeof(float), s, F32(p.q), F32(p.kv),
+                           I32(p.ids[l - 1]), n, p.k, p.H, p.hd, scale, F32(p.att));
+        DYGNN_LAUNCH_CHECK();
+        if (int rc = gemm_nt<false>(F32(p.att), Lw.res_w, Lw.res_b, F32(p.fc), n, p.Dq, p.Dq, p.Dq, s)) return rc;
+        hipLaunchKernelGGL(k_tgat_post, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, s, F32(p.fc), F32(p.q_in), Lw.ln_w, Lw.ln_b, node_feat, I32(p.ids[l - 1]),
+                           n, p.Dq, p.Fn, F32(p.merge_in));
+        DYGNN_LAUNCH_CHECK();
+        if (int rc = gemm_nt<true>(F32(p.merge_in), Lw.fc1_w, Lw.fc1_b, F32(p.hid), n, p.Fn, p.Dq + p.Fn, p.Fn, s)) return rc;
+        if (int rc = gemm_nt<false>(F32(p.hid), Lw.fc2_w, Lw.fc2_b, F32(p.h[l]), n, p.Fn, p.Fn, p.Fn, s)) return rc;
+    }
+    hipLaunchKernelGGL(k_split_out, dim3((unsigned)ceil_div(2 * batch * p.Fn, 256)), dim3(256), 0, s, F32(p.h[p.L]), batch, p.Fn, out_src, out_dst);
+    DYGNN_LAUNCH_CHECK();
+    return DYGNN_OK;
+}

@@ -206,3 +206,45 @@ def random_negative_dst(rs: np.random.RandomState, unique_dst: np.ndarray, size:
     unique destination ids (utils/utils.py NegativeEdgeSampler.random_sample)."""
     idx = rs.randint(0, len(unique_dst), size)
     return unique_dst[idx].astype(np.int64)
+
+
+def tgat_param_shapes(node_feat_dim: int = NODE_FEAT_DIM, edge_feat_dim: int = NODE_FEAT_DIM, time_feat_dim: int = 100,
+                      num_layers: int = 2) -> Dict[str, Tuple[int, ...]]:
+    """state_dict of the reference TGAT (models/TGAT.py:34-45, models/modules.py:121-133, :53-54)."""
+    Dq, Dkv = node_feat_dim + time_feat_dim, node_feat_dim + edge_feat_dim + time_feat_dim
+    shapes: Dict[str, Tuple[int, ...]] = {"time_encoder.w.weight": (time_feat_dim, 1), "time_encoder.w.bias": (time_feat_dim,)}
+    for l in range(num_layers):
+        p = f"temporal_conv_layers.{l}."
+        shapes[p + "query_projection.weight"] = (Dq, Dq)
+        shapes[p + "key_projection.weight"] = (Dq, Dkv)
+        shapes[p + "value_projection.weight"] = (Dq, Dkv)
+        shapes[p + "layer_norm.weight"] = (Dq,)
+        shapes[p + "layer_norm.bias"] = (Dq,)
+        shapes[p + "residual_fc.weight"] = (Dq, Dq)
+        shapes[p + "residual_fc.bias"] = (Dq,)
+    for l in range(num_layers):
+        p = f"merge_layers.{l}."
+        shapes[p + "fc1.weight"] = (node_feat_dim, Dq + node_feat_dim)
+        shapes[p + "fc1.bias"] = (node_feat_dim,)
+        shapes[p + "fc2.weight"] = (node_feat_dim, node_feat_dim)
+        shapes[p + "fc2.bias"] = (node_feat_dim,)
+    return shapes
+
+
+def make_tgat_params(seed: int, node_feat_dim: int = NODE_FEAT_DIM, edge_feat_dim: int = NODE_FEAT_DIM, time_feat_dim: int = 100,
+                     num_layers: int = 2) -> Dict[str, np.ndarray]:
+    rs = np.random.RandomState(seed)
+    out: Dict[str, np.ndarray] = {}
+    for key, shape in tgat_param_shapes(node_feat_dim, edge_feat_dim, time_feat_dim, num_layers).items():
+        if key == "time_encoder.w.weight":
+            base = (1.0 / 10 ** np.linspace(0, 9, time_feat_dim, dtype=np.float32)).reshape(shape)
+            val = base * (1.0 + 0.01 * rs.uniform(-1, 1, size=shape))
+        elif key == "time_encoder.w.bias":
+            val = 0.1 * rs.uniform(-1, 1, size=shape)
+        elif "layer_norm" in key:
+            val = (1.0 if key.endswith("weight") else 0.0) + 0.1 * rs.uniform(-1, 1, size=shape)
+        else:
+            fan_in = shape[1] if len(shape) == 2 else out[key[:-4] + "weight"].shape[1]
+            val = rs.uniform(-1, 1, size=shape) / np.sqrt(fan_in)
+        out[key] = np.ascontiguousarray(val, dtype=np.float32)
+    return out

@@ -1,0 +1,110 @@
+"""Drop-in for the reference `TGAT` backbone (models/TGAT.py:9-147): same constructor, same
+`compute_src_dst_node_temporal_embeddings(src_node_ids, dst_node_ids, node_interact_times, num_neighbors)` /
+`compute_node_temporal_embeddings` / `set_neighbor_sampler` signatures, same parameter names (state_dict
+compatible); the forward runs in libdygnn_hip.so (`dygnn_tgat_forward`).  Inference only, `recent` sampling."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _capi
+from .modules import MergeLayer, TimeEncoder
+from .neighbor_sampler import NeighborSampler
+
+
+class MultiHeadAttention(nn.Module):
+    """Parameters of models/modules.py:99-135 (bias-free q/k/v projections, LayerNorm, residual_fc)."""
+
+    def __init__(self, node_feat_dim: int, edge_feat_dim: int, time_feat_dim: int, num_heads: int = 2, dropout: float = 0.1):
+        super().__init__()
+        self.node_feat_dim, self.edge_feat_dim, self.time_feat_dim, self.num_heads = node_feat_dim, edge_feat_dim, time_feat_dim, num_heads
+        self.query_dim = node_feat_dim + time_feat_dim
+        self.key_dim = node_feat_dim + edge_feat_dim + time_feat_dim
+        assert self.query_dim % num_heads == 0, "The sum of node_feat_dim and time_feat_dim should be divided by num_heads!"
+        self.head_dim = self.query_dim // num_heads
+        self.query_projection = nn.Linear(self.query_dim, num_heads * self.head_dim, bias=False)
+        self.key_projection = nn.Linear(self.key_dim, num_heads * self.head_dim, bias=False)
+        self.value_projection = nn.Linear(self.key_dim, num_heads * self.head_dim, bias=False)
+        self.scaling_factor = self.head_dim ** -0.5
+        self.layer_norm = nn.LayerNorm(self.query_dim)
+        self.residual_fc = nn.Linear(num_heads * self.head_dim, self.query_dim)
+        self.dropout = nn.Dropout(dropout)
+
+
+class TGAT(nn.Module):
+
+    def __init__(self, node_raw_features: np.ndarray, edge_raw_features: np.ndarray, neighbor_sampler: NeighborSampler,
+                 time_feat_dim: int, num_layers: int = 2, num_heads: int = 2, dropout: float = 0.1, device: str = "cpu"):
+        super().__init__()
+        self.node_raw_features = torch.from_numpy(np.ascontiguousarray(node_raw_features, dtype=np.float32)).to(device)
+        self.edge_raw_features = torch.from_numpy(np.ascontiguousarray(edge_raw_features, dtype=np.float32)).to(device)
+        self.neighbor_sampler = neighbor_sampler
+        self.node_feat_dim = self.node_raw_features.shape[1]
+        self.edge_feat_dim = self.edge_raw_features.shape[1]
+        self.time_feat_dim = time_feat_dim
+        self.num_layers = num_layers
+        self.num_heads = num_heads
+        self.dropout = dropout
+        self.time_encoder = TimeEncoder(time_dim=time_feat_dim)
+        self.temporal_conv_layers = nn.ModuleList([MultiHeadAttention(self.node_feat_dim, self.edge_feat_dim, self.time_feat_dim,
+                                                                      self.num_heads, self.dropout) for _ in range(num_layers)])
+        self.merge_layers = nn.ModuleList([MergeLayer(input_dim1=self.node_feat_dim + self.time_feat_dim, input_dim2=self.node_feat_dim,
+                                                      hidden_dim=self.node_feat_dim, output_dim=self.node_feat_dim) for _ in range(num_layers)])
+        self._lib = _capi.load()
+        self._workspace: Dict[tuple, torch.Tensor] = {}
+
+    def set_neighbor_sampler(self, neighbor_sampler: NeighborSampler):
+        """models/TGAT.py:138-147."""
+        self.neighbor_sampler = neighbor_sampler
+        if self.neighbor_sampler.sample_neighbor_strategy in ["uniform", "time_interval_aware"]:
+            assert self.neighbor_sampler.seed is not None
+            self.neighbor_sampler.reset_random_state()
+
+    def compute_src_dst_node_temporal_embeddings(self, src_node_ids, dst_node_ids, node_interact_times,
+                                                 num_neighbors: int = 20) -> Tuple[torch.Tensor, torch.Tensor]:
+        """models/TGAT.py:48-64: two float32 tensors [B, node_feat_dim] on the model's device."""
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("training-mode forward / backward through the HIP path is not built yet (SURVEY.md §8f-1)")
+        self.neighbor_sampler._require_recent()
+        dev = self.merge_layers[0].fc1.weight.device
+        if dev.type != "cuda":
+            raise _capi.DygnnError("dyglib_amd.TGAT runs on an MI355X only; there is no CPU fallback")
+        if self.node_raw_features.device != dev:
+            self.node_raw_features = self.node_raw_features.to(dev)
+            self.edge_raw_features = self.edge_raw_features.to(dev)
+        to_dev = lambda x, dt: (x.to(device=dev, dtype=dt).contiguous() if isinstance(x, torch.Tensor)
+                                else torch.from_numpy(np.ascontiguousarray(x, dtype={torch.int64: np.int64, torch.float64: np.float64}[dt])).to(dev))
+        src, dst, tms = to_dev(src_node_ids, torch.int64), to_dev(dst_node_ids, torch.int64), to_dev(node_interact_times, torch.float64)
+        B = src.numel()
+        assert dst.numel() == B and tms.numel() == B
+        out_src = torch.empty((B, self.node_feat_dim), dtype=torch.float32, device=dev)
+        out_dst = torch.empty_like(out_src)
+        if B == 0:
+            return out_src, out_dst
+        cfg = _capi.TgatConfig(self.node_feat_dim, self.edge_feat_dim, self.time_feat_dim, self.num_layers, self.num_heads, int(num_neighbors))
+        w = _capi.TgatWeights()
+        w.time_w, w.time_b = self.time_encoder.w.weight.data_ptr(), self.time_encoder.w.bias.data_ptr()
+        for l in range(self.num_layers):
+            a, m, L = self.temporal_conv_layers[l], self.merge_layers[l], w.layers[l]
+            L.query_w, L.key_w, L.value_w = a.query_projection.weight.data_ptr(), a.key_projection.weight.data_ptr(), a.value_projection.weight.data_ptr()
+            L.ln_w, L.ln_b = a.layer_norm.weight.data_ptr(), a.layer_norm.bias.data_ptr()
+            L.res_w, L.res_b = a.residual_fc.weight.data_ptr(), a.residual_fc.bias.data_ptr()
+            L.fc1_w, L.fc1_b, L.fc2_w, L.fc2_b = m.fc1.weight.data_ptr(), m.fc1.bias.data_ptr(), m.fc2.weight.data_ptr(), m.fc2.bias.data_ptr()
+        nbytes = self._lib.dygnn_tgat_workspace_bytes(C.byref(cfg), B)
+        if nbytes == 0:
+            _capi.check(-1)                      # AssertionError with the library's message (e.g. num_neighbors <= 0)
+        key = (B, int(num_neighbors), torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._workspace.get(key)
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            if len(self._workspace) > 8:
+                self._workspace.clear()
+            ws = self._workspace[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _capi.check(self._lib.dygnn_tgat_forward(C.byref(cfg), C.byref(w), self.neighbor_sampler.csr.on_device(dev),
+                                                 self.node_raw_features.data_ptr(), self.edge_raw_features.data_ptr(),
+                                                 src.data_ptr(), dst.data_ptr(), tms.data_ptr(), B, out_src.data_ptr(), out_dst.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), _capi.current_stream_ptr()))
+        return out_src, out_dst

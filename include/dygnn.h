@@ -168,6 +168,39 @@ int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg_host, const dygnn_
                             void* workspace, size_t workspace_bytes,
                             const dygnn_dygformer_taps* taps_host, int32_t impl, dygnn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * TGAT.compute_src_dst_node_temporal_embeddings (models/TGAT.py:48-136), eval mode, `recent`
+ * sampling: L temporal-attention layers (MultiHeadAttention models/modules.py:99-206, mask =
+ * neighbour id == 0 -> -1e10, post-LayerNorm) each followed by MergeLayer([out | raw node feat])
+ * (models/TGAT.py:134).  Hop-(l+1) queries use the float32 neighbour times (models/TGAT.py:107-110).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dygnn_tgat_config {
+    int32_t node_feat_dim, edge_feat_dim, time_feat_dim;   /* 172, 172, 100; each a multiple of 4   */
+    int32_t num_layers;                                    /* 1..3                  models/TGAT.py:28 */
+    int32_t num_heads;                                     /* (F_n+F_t) % H == 0    modules.py:120   */
+    int32_t num_neighbors;                                 /* k <= 64               models/TGAT.py:49 */
+} dygnn_tgat_config;
+
+typedef struct dygnn_tgat_layer_weights {                  /* state_dict keys, PyTorch [out,in] layout */
+    const float *query_w;                                  /* temporal_conv_layers.l.query_projection.weight [Dq,Dq]  */
+    const float *key_w, *value_w;                          /* ...key_projection / value_projection.weight    [Dq,Dkv] */
+    const float *ln_w, *ln_b;                              /* ...layer_norm.{weight,bias}                     [Dq]     */
+    const float *res_w, *res_b;                            /* ...residual_fc.{weight,bias}              [Dq,Dq],[Dq]   */
+    const float *fc1_w, *fc1_b;                            /* merge_layers.l.fc1                 [F_n,Dq+F_n],[F_n]    */
+    const float *fc2_w, *fc2_b;                            /* merge_layers.l.fc2                 [F_n,F_n],[F_n]       */
+} dygnn_tgat_layer_weights;
+
+typedef struct dygnn_tgat_weights {
+    const float *time_w, *time_b;                          /* time_encoder.w                                           */
+    dygnn_tgat_layer_weights layers[DYGNN_MAX_LAYERS];
+} dygnn_tgat_weights;
+
+size_t dygnn_tgat_workspace_bytes(const dygnn_tgat_config* cfg_host, int64_t batch);
+int dygnn_tgat_forward(const dygnn_tgat_config* cfg_host, const dygnn_tgat_weights* w_host, const dygnn_csr* csr_host,
+                       const float* node_feat, const float* edge_feat,
+                       const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
+                       float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
+
 /* Caller-side link predictor, fused: sigmoid(MergeLayer(a,b)) with
  * MergeLayer = fc2(relu(fc1(cat(a,b)))) (models/modules.py:57-68; evaluate_models_utils.py:140-141).
  * a,b [n,dim]; fc1 [hidden, 2*dim]; fc2 [1,hidden]; out [n]. */

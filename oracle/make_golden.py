@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 from models.DyGFormer import DyGFormer as RefDyGFormer          # noqa: E402  (reference)
 from models.modules import MergeLayer as RefMergeLayer          # noqa: E402  (reference)
+from models.TGAT import TGAT as RefTGAT                         # noqa: E402  (reference)
 from utils.DataLoader import Data as RefData                    # noqa: E402  (reference)
 from utils.utils import get_neighbor_sampler as ref_get_neighbor_sampler  # noqa: E402  (reference)
 
@@ -91,11 +92,34 @@ def run_case(name: str) -> dict:
     return out
 
 
+def run_tgat_case(name: str) -> dict:
+    c = gc.build_tgat_case(name)
+    d, cfg = c["data"], c["tgat_cfg"]
+    ref_data = RefData(d.src_node_ids, d.dst_node_ids, d.node_interact_times, d.edge_ids, d.labels)
+    sampler = ref_get_neighbor_sampler(ref_data, sample_neighbor_strategy="recent", seed=1)
+    model = RefTGAT(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"], num_layers=cfg["num_layers"],
+                    num_heads=cfg["num_heads"], dropout=0.1, device="cpu")
+    r = model.load_state_dict({k: torch.from_numpy(v) for k, v in c["tgat_params"].items()}, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    model.eval()
+    with torch.no_grad():
+        se, de = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"], num_neighbors=cfg["num_neighbors"])
+        nse, nde = model.compute_src_dst_node_temporal_embeddings(c["src"], c["neg_dst"], c["times"], num_neighbors=cfg["num_neighbors"])
+    return {"src_emb": se.numpy(), "dst_emb": de.numpy(), "neg_src_emb": nse.numpy(), "neg_dst_emb": nde.numpy(),
+            "torch_version": np.array(torch.__version__)}
+
+
 def main():
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(8)
-    names = sys.argv[1:] or list(gc.CASES)
+    names = sys.argv[1:] or (list(gc.CASES) + list(gc.TGAT_CASES))
     for name in names:
+        if name in gc.TGAT_CASES:
+            out = run_tgat_case(name)
+            path = os.path.join(gc.GOLDEN_DIR, name + ".npz")
+            np.savez_compressed(path, **out)
+            print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB  B={len(out['src_emb'])}")
+            continue
         out = run_case(name)
         path = os.path.join(gc.GOLDEN_DIR, name + ".npz")
         np.savez_compressed(path, **out)

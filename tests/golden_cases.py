@@ -37,6 +37,13 @@ CASES = {
                         patch_size=8, max_len=512, param_seed=105, batch="tail6", neg_seed=9),
 }
 
+# TGAT (BASELINE config 3) recipes reuse the graphs above: (graph case, num_layers, num_neighbors, param seed)
+TGAT_CASES = {
+    "tgat_bip_l2_k20": dict(graph="bip_p2_l64", num_layers=2, num_neighbors=20, param_seed=201),
+    "tgat_gen_l2_k5": dict(graph="gen_p1_l32", num_layers=2, num_neighbors=5, param_seed=202),
+    "tgat_hub_l1_k10": dict(graph="hub_p4_l48", num_layers=1, num_neighbors=10, param_seed=203),
+}
+
 TAP_ROWS = 3          # intermediates are stored for the first TAP_ROWS rows only
 SAMPLER_KS = (1, 10, 20)
 
@@ -78,3 +85,11 @@ def load_golden(name: str):
     path = os.path.join(GOLDEN_DIR, name + ".npz")
     with np.load(path, allow_pickle=False) as z:
         return {k: z[k] for k in z.files}
+
+
+def build_tgat_case(name: str):
+    r = TGAT_CASES[name]
+    c = build_case(r["graph"])
+    c["tgat_params"] = syn.make_tgat_params(r["param_seed"], num_layers=r["num_layers"])
+    c["tgat_cfg"] = dict(num_layers=r["num_layers"], num_neighbors=r["num_neighbors"], num_heads=2, time_feat_dim=100)
+    return c

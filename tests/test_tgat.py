@@ -1,0 +1,102 @@
+"""TGAT (BASELINE config 3): the oracle restatement against reference-generated golden vectors (CPU), and the HIP
+path through the C ABI against golden + oracle (GPU).  fp32 tolerance 1e-4 * max(1, max|ref|)."""
+import numpy as np
+import pytest
+import torch
+
+from dyglib_amd import synthetic as syn
+from oracle import dygformer_oracle as orc
+from oracle import tgat_oracle as torc
+from tests import golden_cases as gc
+
+TOL = 1e-4
+
+
+def close(got, want, what=""):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape and np.isfinite(got).all(), what
+    atol = TOL * max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max())
+    assert err <= atol, f"{what}: max abs err {err:.3e} > {atol:.3e}"
+
+
+@pytest.fixture(scope="module", params=list(gc.TGAT_CASES))
+def case(request):
+    c = gc.build_tgat_case(request.param)
+    g = gc.load_golden(request.param)
+    d = c["data"]
+    adj = orc.OracleAdjacency(d.src_node_ids, d.dst_node_ids, d.edge_ids, d.node_interact_times)
+    return request.param, c, g, adj
+
+
+def test_oracle_matches_reference_golden(case):
+    name, c, g, adj = case
+    cfg = c["tgat_cfg"]
+    s, d = torc.tgat_forward(c["tgat_params"], c["node_feat"], c["edge_feat"], adj, c["src"], c["dst"], c["times"],
+                             cfg["num_layers"], cfg["num_neighbors"], cfg["num_heads"])
+    close(s.numpy(), g["src_emb"], name + " src")
+    close(d.numpy(), g["dst_emb"], name + " dst")
+    ns, nd = torc.tgat_forward(c["tgat_params"], c["node_feat"], c["edge_feat"], adj, c["src"], c["neg_dst"], c["times"],
+                               cfg["num_layers"], cfg["num_neighbors"], cfg["num_heads"])
+    close(nd.numpy(), g["neg_dst_emb"], name + " neg dst")
+
+
+def test_state_dict_keys_match_reference():
+    from dyglib_amd import TGAT, NeighborSampler
+    from dyglib_amd.temporal_csr import TemporalCSR
+    data, nf, ef = syn.make_bipartite_graph(5, 3, 20, seed=0)
+    sampler = NeighborSampler(None, "recent", seed=0, csr=TemporalCSR.from_interactions(
+        data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times), device="cpu")
+    m = TGAT(nf, ef, sampler, time_feat_dim=100, num_layers=2, num_heads=2, dropout=0.1, device="cpu")
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == syn.tgat_param_shapes(num_layers=2)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_tgat_params(1).items()}, strict=True)
+
+
+def _model(c, device="cuda:0"):
+    from dyglib_amd import TGAT, get_neighbor_sampler
+    cfg = c["tgat_cfg"]
+    sampler = get_neighbor_sampler(c["data"], "recent", seed=1, device=device)
+    m = TGAT(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"], num_layers=cfg["num_layers"],
+             num_heads=cfg["num_heads"], dropout=0.1, device=device)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in c["tgat_params"].items()}, strict=True)
+    return m.to(device).eval()
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden(case):
+    name, c, g, adj = case
+    m = _model(c)
+    k = c["tgat_cfg"]["num_neighbors"]
+    with torch.no_grad():
+        s, d = m.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"], num_neighbors=k)
+        ns, nd = m.compute_src_dst_node_temporal_embeddings(c["src"], c["neg_dst"], c["times"], num_neighbors=k)
+        s2, d2 = m.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"], num_neighbors=k)
+    assert s.shape == (len(c["src"]), 172) and s.dtype == torch.float32 and s.is_cuda
+    close(s.cpu().numpy(), g["src_emb"], name + " src")
+    close(d.cpu().numpy(), g["dst_emb"], name + " dst")
+    close(ns.cpu().numpy(), g["neg_src_emb"], name + " neg src")
+    close(nd.cpu().numpy(), g["neg_dst_emb"], name + " neg dst")
+    assert torch.equal(s, s2) and torch.equal(d, d2)
+    with pytest.raises(AssertionError):
+        m.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"], num_neighbors=0)     # utils/utils.py:157
+
+
+@pytest.mark.gpu
+def test_hip_reddit_shape_batch_against_oracle():
+    """BASELINE config 3 shape: k=20, 2 layers, B=200 on a mid-size graph, vs the oracle."""
+    from dyglib_amd import TGAT, get_neighbor_sampler
+    data, nf, ef = syn.make_bipartite_graph(500, 60, 30000, seed=31)
+    nf[1:] = np.random.RandomState(5).standard_normal(nf[1:].shape).astype(np.float32) * 0.5
+    params = syn.make_tgat_params(9)
+    sampler = get_neighbor_sampler(data, "recent", seed=1, device="cuda:0")
+    m = TGAT(nf, ef, sampler, 100, num_layers=2, num_heads=2, dropout=0.1, device="cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    m = m.to("cuda:0").eval()
+    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    idx = np.arange(data.num_interactions - 200, data.num_interactions)
+    src, dst, t = data.src_node_ids[idx], data.dst_node_ids[idx], data.node_interact_times[idx]
+    os_, od = torc.tgat_forward(params, nf, ef, adj, src, dst, t, 2, 20, 2)
+    with torch.no_grad():
+        gs, gd = m.compute_src_dst_node_temporal_embeddings(src, dst, t, num_neighbors=20)
+    close(gs.cpu().numpy(), os_.numpy(), "src")
+    close(gd.cpu().numpy(), od.numpy(), "dst")
