@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Secondary benchmark (BASELINE config 3): TGAT link-prediction forward, Reddit-shaped synthetic graph
+(10,000 + 984 nodes, 672,447 edges), k = 20, 2 layers, batch 200: pos call + neg call + MergeLayer+sigmoid per step.
+Prints one JSON line (same fields as bench.py; not the headline metric)."""
+import argparse, json, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dyglib_amd import TGAT, MergeLayer, get_neighbor_sampler, synthetic as syn
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--edges", type=int, default=672447); ap.add_argument("--cpu-steps", type=int, default=2)
+args = ap.parse_args()
+dev = "cuda:0"
+B, K = 200, 20
+data, nf, ef = syn.make_bipartite_graph(10000, 984, args.edges, seed=0)
+params, mparams = syn.make_tgat_params(0), syn.make_merge_layer_params(1000)
+sampler = get_neighbor_sampler(data, "recent", seed=1, device=dev)
+model = TGAT(nf, ef, sampler, 100, num_layers=2, num_heads=2, dropout=0.1, device=dev)
+model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+merge = MergeLayer(172, 172, 172, 1); merge.load_state_dict({k: torch.from_numpy(v) for k, v in mparams.items()})
+model, merge = model.to(dev).eval(), merge.to(dev).eval()
+E = data.num_interactions; first = int(E * 0.7); nb = (E - first) // B
+rs = np.random.RandomState(2); ud = np.unique(data.dst_node_ids)
+batches = []
+for i in range(min(nb, args.steps + args.warmup)):
+    sl = slice(first + i * B, first + (i + 1) * B)
+    batches.append(tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in
+                         (data.src_node_ids[sl], data.dst_node_ids[sl], syn.random_negative_dst(rs, ud, B), data.node_interact_times[sl])))
+def step(i):
+    s, d, n, t = batches[i % len(batches)]
+    with torch.no_grad():
+        a, b_ = model.compute_src_dst_node_temporal_embeddings(s, d, t, num_neighbors=K)
+        c, e = model.compute_src_dst_node_temporal_embeddings(s, n, t, num_neighbors=K)
+        return merge.link_probabilities(a, b_), merge.link_probabilities(c, e)
+for i in range(args.warmup): step(i)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(args.steps): step(args.warmup + i)
+torch.cuda.synchronize(); el = time.perf_counter() - t0
+out = {"metric": "edges/sec (link-prediction fwd) TGAT Reddit-shaped", "value": round(args.steps * B / el, 1), "unit": "edges/s",
+       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "dtype": "f32", "data": "synthetic",
+       "config": {"workload": f"TGAT link-prediction forward, synthetic Reddit-shaped graph (10000+984 nodes, {args.edges} edges), k=20, 2 layers, batch=200"},
+       # 10.19 MFLOP per node-layer x 17,600 node-layers per step
+       "roofline": {"bound": "mfma", "achieved": round(179.4e9 / (el / args.steps) / 1e12, 3), "peak": 157.3, "unit": "TFLOP/s",
+                    "frac": round(179.4e9 / (el / args.steps) / 157.3e12, 4), "traffic": None}}
+if args.cpu_steps > 0:
+    from oracle import dygformer_oracle as orc, tgat_oracle as torc
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    nft, eft = torch.from_numpy(nf), torch.from_numpy(ef)
+    tp = {k: torch.from_numpy(v) for k, v in params.items()}
+    t0 = time.perf_counter()
+    for i in range(args.cpu_steps):
+        s, d, n, t = [x.cpu().numpy() for x in batches[i]]
+        torc.tgat_forward(tp, nft, eft, adj, s, d, t, 2, K, 2); torc.tgat_forward(tp, nft, eft, adj, s, n, t, 2, K, 2)
+    cel = time.perf_counter() - t0
+    out["cpu_baseline"] = {"value": round(args.cpu_steps * B / cel, 1), "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+                           "sample": f"{args.cpu_steps} of the same steps ({cel:.1f} s), oracle/tgat_oracle.py"}
+print(json.dumps(out))
