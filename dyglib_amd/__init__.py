@@ -8,7 +8,7 @@ The compute lives in dyglib_amd/csrc (C ABI: include/dygnn.h).  There is no CPU 
 """
 from .synthetic import InteractionData  # noqa: F401
 
-__all__ = ["DyGFormer", "TGAT", "MergeLayer", "TimeEncoder", "NeighborSampler", "get_neighbor_sampler", "TemporalCSR",
+__all__ = ["DyGFormer", "TGAT", "MemoryModel", "MergeLayer", "TimeEncoder", "NeighborSampler", "get_neighbor_sampler", "TemporalCSR",
            "count_nodes_appearances", "InteractionData"]
 
 
@@ -17,6 +17,9 @@ def __getattr__(name):
     if name in ("DyGFormer",):
         from .dygformer import DyGFormer
         return DyGFormer
+    if name == "MemoryModel":
+        from .memory_model import MemoryModel
+        return MemoryModel
     if name == "TGAT":
         from .tgat import TGAT
         return TGAT

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported first: see module docstring)
 from . import _build
 
 DYGNN_MAX_LAYERS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -64,6 +64,14 @@ class TgatWeights(C.Structure):
     _fields_ = [("time_w", C.c_void_p), ("time_b", C.c_void_p), ("layers", TgatLayerWeights * DYGNN_MAX_LAYERS)]
 
 
+class GruWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+
+
+class TgnState(C.Structure):
+    _fields_ = [("num_nodes", C.c_int64)] + [(n, C.c_void_p) for n in ("memory", "last_update", "msg", "msg_time", "has_msg")]
+
+
 class DygformerTaps(C.Structure):
     _fields_ = [("seq_lens", C.c_void_p), ("encoder_input", C.c_void_p), ("layer_out", C.c_void_p * DYGNN_MAX_LAYERS),
                 ("phase_cycles", C.c_void_p)]
@@ -96,6 +104,10 @@ SIGNATURES = {
     "dygnn_tgat_workspace_bytes": (C.c_size_t, [C.POINTER(TgatConfig), C.c_int64]),
     "dygnn_tgat_forward": (C.c_int, [C.POINTER(TgatConfig), C.POINTER(TgatWeights), C.POINTER(Csr), C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dygnn_tgn_workspace_bytes": (C.c_size_t, [C.POINTER(TgatConfig), C.c_int64, C.c_int64]),
+    "dygnn_tgn_forward": (C.c_int, [C.POINTER(TgatConfig), C.POINTER(TgatWeights), C.POINTER(GruWeights), C.POINTER(Csr), C.c_void_p, C.c_void_p,
+                                    C.POINTER(TgnState), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dygnn_merge_layer_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

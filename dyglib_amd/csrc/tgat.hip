@@ -300,9 +300,10 @@ extern "C" size_t dygnn_tgat_workspace_bytes(const dygnn_tgat_config* cfg, int64
     return make_tgat_plan(*cfg, batch).total;
 }
 
-extern "C" int dygnn_tgat_forward(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_csr* csr, const float* node_feat,
-                                  const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
-                                  float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
+namespace dygnn {
+static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_csr* csr, const float* node_feat,
+                             const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
+                             float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
     if (int rc = check_tgat(cfg)) return rc;
     DYGNN_REQUIRE(w && w->time_w && w->time_b, "tgat: null weights");
     DYGNN_REQUIRE(csr && csr->indptr && csr->num_nodes >= 1, "tgat: bad csr");
@@ -359,5 +360,157 @@ extern "C" int dygnn_tgat_forward(const dygnn_tgat_config* cfg, const dygnn_tgat
     }
     hipLaunchKernelGGL(k_split_out, dim3((unsigned)ceil_div(2 * batch * p.Fn, 256)), dim3(256), 0, s, F32(p.h[p.L]), batch, p.Fn, out_src, out_dst);
     DYGNN_LAUNCH_CHECK();
+    return DYGNN_OK;
+}
+
+// ================================================================================================
+// TGN (BASELINE config 5; reference models/MemoryModel.py): memory bank + last-message aggregation + GRU update +
+// the same temporal graph attention over (memory + raw) node features.
+// State (owned by the caller, one per model): memory M [N][Fn], last-update time U [N] (float32), and ONE pending raw
+// message per node (msg [N][2Fn+Ft+Fe], its float64 time, a flag): the reference keeps a Python list per node
+// (MemoryModel.py:389-407) but its aggregator only ever reads the last element (:284-291), and lists are cleared
+// whole (:400-407), so the last message is the entire observable state.
+// ================================================================================================
+__global__ void k_tgn_gates(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ M, const float* __restrict__ raw,
+                            const int32_t* __restrict__ has_msg, int64_t N, int Fn, float* __restrict__ Mnew, float* __restrict__ feat0) {
+    // nn.GRUCell: r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Fn) return;
+    const int64_t node = i / Fn;
+    const int f = (int)(i % Fn);
+    const float h = M[i];
+    float hn = h;
+    if (has_msg[node]) {
+        const float* a = gi + node * 3 * Fn;
+        const float* b = gh + node * 3 * Fn;
+        const float r = 1.0f / (1.0f + expf(-(a[f] + b[f])));
+        const float z = 1.0f / (1.0f + expf(-(a[Fn + f] + b[Fn + f])));
+        const float nn = tanhf(a[2 * Fn + f] + r * b[2 * Fn + f]);
+        hn = (1.0f - z) * nn + z * h;
+    }
+    Mnew[i] = hn;                                  // updated memories "just for computation" (MemoryModel.py:461-487)
+    feat0[i] = hn + raw[i];                        // layer-0 node features = memory + raw (MemoryModel.py:609)
+}
+
+// persist the update for the batch nodes that have a pending message and clear it (MemoryModel.py:142-145, :425-459)
+__global__ void k_tgn_persist(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t B, const float* __restrict__ Mnew,
+                              const double* __restrict__ msg_t, int Fn, float* __restrict__ M, float* __restrict__ U, const int32_t* __restrict__ has_msg) {
+    const int64_t r = blockIdx.x;                  // 0..2B-1 (a node occurring several times is written several times with the same values)
+    const int64_t node = r < B ? src[r] : dst[r - B];
+    if (has_msg[node]) {
+        for (int f = threadIdx.x; f < Fn; f += blockDim.x) M[node * Fn + f] = Mnew[node * Fn + f];
+        if (threadIdx.x == 0) U[node] = (float)msg_t[node];
+    }
+}
+__global__ void k_tgn_clear(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t B, int32_t* __restrict__ has_msg) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < 2 * B) has_msg[r < B ? src[r] : dst[r - B]] = 0;
+}
+// winner per node for one role = the LAST occurrence in batch order (list append order, MemoryModel.py:244-249)
+__global__ void k_tgn_winner(const int64_t* __restrict__ who, int64_t B, int32_t* __restrict__ win) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) atomicMax(&win[who[i]], (int32_t)i);
+}
+// new raw message of role-node who[i]: [M[who] | M[other] | cos(w (t - U[who]) + b) | edge feature]  (MemoryModel.py:223-241)
+__global__ __launch_bounds__(256) void k_tgn_message(const int64_t* __restrict__ who, const int64_t* __restrict__ other, const double* __restrict__ times,
+                                                       const int64_t* __restrict__ eids, int64_t B, const float* __restrict__ M, const float* __restrict__ U,
+                                                       const float* __restrict__ edge_feat, const float* __restrict__ tw, const float* __restrict__ tb,
+                                                       int Fn, int Fe, int Ft, const int32_t* __restrict__ win, float* __restrict__ msg,
+                                                       double* __restrict__ msg_t, int32_t* __restrict__ has_msg) {
+    const int64_t i = blockIdx.x;
+    const int64_t node = who[i];
+    if (win[node] != (int32_t)i) return;           // only the last occurrence is observable
+    const int64_t o = other[i];
+    const int D = 2 * Fn + Ft + Fe;
+    const float dt = (float)times[i] - U[node];    // float32 - float32 (MemoryModel.py:232-233)
+    float* m = msg + node * D;
+    for (int f = threadIdx.x; f < D; f += blockDim.x) {
+        float v;
+        if (f < Fn) v = M[node * Fn + f];
+        else if (f < 2 * Fn) v = M[o * Fn + (f - Fn)];
+        else if (f < 2 * Fn + Ft) v = cosf(fmaf(dt, tw[f - 2 * Fn], tb[f - 2 * Fn]));
+        else v = edge_feat[(size_t)eids[i] * Fe + (f - 2 * Fn - Ft)];
+        m[f] = v;
+    }
+    if (threadIdx.x == 0) { msg_t[node] = times[i]; has_msg[node] = 1; }
+}
+__global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+struct TgnPlan { size_t gi, gh, Mnew, feat0, win, tgat, total; };
+static TgnPlan make_tgn_plan(const dygnn_tgat_config& c, int64_t N, int64_t B) {
+    TgnPlan p{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~size_t(255); return r; };
+    p.gi = take((size_t)N * 3 * c.node_feat_dim * sizeof(float));
+    p.gh = take((size_t)N * 3 * c.node_feat_dim * sizeof(float));
+    p.Mnew = take((size_t)N * c.node_feat_dim * sizeof(float));
+    p.feat0 = take((size_t)N * c.node_feat_dim * sizeof(float));
+    p.win = take((size_t)N * sizeof(int32_t));
+    p.tgat = take(make_tgat_plan(c, B).total);
+    p.total = o;
+    return p;
+}
+}  // namespace dygnn
+
+extern "C" int dygnn_tgat_forward(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_csr* csr, const float* node_feat,
+                                  const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
+                                  float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
+    return tgat_forward_impl(cfg, w, csr, node_feat, edge_feat, src, dst, times, batch, out_src, out_dst, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t dygnn_tgn_workspace_bytes(const dygnn_tgat_config* cfg, int64_t num_nodes, int64_t batch) {
+    if (check_tgat(cfg) != DYGNN_OK || batch < 0 || num_nodes < 1) return 0;
+    return make_tgn_plan(*cfg, num_nodes, batch).total;
+}
+
+extern "C" int dygnn_tgn_forward(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_gru_weights* gru, const dygnn_csr* csr,
+                                 const float* node_feat, const float* edge_feat, const dygnn_tgn_state* st, const int64_t* src, const int64_t* dst,
+                                 const double* times, const int64_t* edge_ids, int64_t batch, int32_t edges_are_positive, float* out_src,
+                                 float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
+    if (int rc = check_tgat(cfg)) return rc;
+    DYGNN_REQUIRE(gru && gru->weight_ih && gru->weight_hh && gru->bias_ih && gru->bias_hh, "tgn: null GRU weights");
+    DYGNN_REQUIRE(st && st->memory && st->last_update && st->msg && st->msg_time && st->has_msg && st->num_nodes >= 1, "tgn: bad state");
+    DYGNN_REQUIRE(batch >= 0 && node_feat && edge_feat && workspace, "tgn: bad arguments");
+    DYGNN_REQUIRE(!edges_are_positive || edge_ids != nullptr, "tgn: edge_ids required for positive edges");   // MemoryModel.py:140
+    if (batch == 0) return DYGNN_OK;
+    const int64_t N = st->num_nodes;
+    const int Fn = cfg->node_feat_dim, Fe = cfg->edge_feat_dim, Ft = cfg->time_feat_dim, Dm = 2 * Fn + Ft + Fe;
+    const TgnPlan p = make_tgn_plan(*cfg, N, batch);
+    if (workspace_bytes < p.total) { set_error("tgn: workspace too small (%zu < %zu bytes)", workspace_bytes, p.total); return DYGNN_E_WORKSPACE; }
+    hipStream_t s = as_stream(stream);
+    char* ws = static_cast<char*>(workspace);
+    float* gi = reinterpret_cast<float*>(ws + p.gi);
+    float* gh = reinterpret_cast<float*>(ws + p.gh);
+    float* Mnew = reinterpret_cast<float*>(ws + p.Mnew);
+    float* feat0 = reinterpret_cast<float*>(ws + p.feat0);
+    int32_t* win = reinterpret_cast<int32_t*>(ws + p.win);
+    // 1. updated memories of ALL nodes (get_updated_memories over range(num_nodes), MemoryModel.py:108-109): two GEMMs + gates
+    if (int rc = gemm_nt<false>(st->msg, gru->weight_ih, gru->bias_ih, gi, N, 3 * Fn, Dm, 3 * Fn, s)) return rc;
+    if (int rc = gemm_nt<false>(st->memory, gru->weight_hh, gru->bias_hh, gh, N, 3 * Fn, Fn, 3 * Fn, s)) return rc;
+    hipLaunchKernelGGL(k_tgn_gates, dim3((unsigned)ceil_div(N * Fn, 256)), dim3(256), 0, s, gi, gh, st->memory, node_feat, st->has_msg, N, Fn, Mnew, feat0);
+    DYGNN_LAUNCH_CHECK();
+    // 2. temporal graph attention over (memory + raw) features (GraphAttentionEmbedding, MemoryModel.py:548-664)
+    if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, ws + p.tgat, p.total - p.tgat, stream)) return rc;
+    if (!edges_are_positive) return DYGNN_OK;
+    // 3. persist + clear for the batch nodes (MemoryModel.py:142-145)
+    hipLaunchKernelGGL(k_tgn_persist, dim3((unsigned)(2 * batch)), dim3(64), 0, s, src, dst, batch, Mnew, st->msg_time, Fn, st->memory, st->last_update, st->has_msg);
+    DYGNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_tgn_clear, dim3((unsigned)ceil_div(2 * batch, 256)), dim3(256), 0, s, src, dst, batch, st->has_msg);
+    DYGNN_LAUNCH_CHECK();
+    // 4. new raw messages: source role first, then destination role (store order, MemoryModel.py:147-161)
+    for (int role = 0; role < 2; ++role) {
+        const int64_t* who = role ? dst : src;
+        const int64_t* other = role ? src : dst;
+        hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, win, N, -1);
+        DYGNN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_tgn_winner, dim3((unsigned)ceil_div(batch, 256)), dim3(256), 0, s, who, batch, win);
+        DYGNN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_tgn_message, dim3((unsigned)batch), dim3(256), 0, s, who, other, times, edge_ids, batch, st->memory, st->last_update, edge_feat,
+                           w->time_w, w->time_b, Fn, Fe, Ft, win, st->msg, st->msg_time, st->has_msg);
+        DYGNN_LAUNCH_CHECK();
+    }
     return DYGNN_OK;
 }

@@ -1,0 +1,177 @@
+"""Drop-in for the reference `MemoryModel` with model_name == 'TGN' (models/MemoryModel.py:9-168): same constructor,
+`compute_src_dst_node_temporal_embeddings(src_node_ids, dst_node_ids, node_interact_times, edge_ids,
+edges_are_positive, num_neighbors)`, `set_neighbor_sampler`, `memory_bank.__init_memory_bank__ / backup_memory_bank /
+reload_memory_bank`, and the same state_dict keys.  The forward, the GRU memory update and the raw-message bookkeeping run
+in libdygnn_hip.so (`dygnn_tgn_forward`).  JODIE / DyRep are not built (not in BASELINE.json's configs)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _capi
+from .modules import MergeLayer, TimeEncoder
+from .neighbor_sampler import NeighborSampler
+from .tgat import MultiHeadAttention
+
+
+class MemoryBank(nn.Module):
+    """memory_bank.{node_memories,node_last_updated_times} are (non-trainable) Parameters like the reference's
+    (MemoryModel.py:317-320).  The per-node Python list of raw messages becomes three device buffers holding the LAST
+    pending message of every node: the aggregator only reads the last element (:284-291) and lists are cleared whole."""
+
+    def __init__(self, num_nodes: int, memory_dim: int, message_dim: int):
+        super().__init__()
+        self.num_nodes, self.memory_dim, self.message_dim = num_nodes, memory_dim, message_dim
+        self.node_memories = nn.Parameter(torch.zeros((num_nodes, memory_dim)), requires_grad=False)
+        self.node_last_updated_times = nn.Parameter(torch.zeros(num_nodes), requires_grad=False)
+        self.msg = self.msg_time = self.has_msg = None
+        self.__init_memory_bank__()
+
+    def _alloc(self):
+        dev = self.node_memories.device
+        if self.msg is None or self.msg.device != dev:
+            self.msg = torch.zeros((self.num_nodes, self.message_dim), dtype=torch.float32, device=dev)
+            self.msg_time = torch.zeros(self.num_nodes, dtype=torch.float64, device=dev)
+            self.has_msg = torch.zeros(self.num_nodes, dtype=torch.int32, device=dev)
+
+    def __init_memory_bank__(self):
+        """MemoryModel.py:322-329: called at the start of every epoch."""
+        self.node_memories.data.zero_()
+        self.node_last_updated_times.data.zero_()
+        self.msg = None
+        self._alloc()
+
+    def backup_memory_bank(self):
+        """MemoryModel.py:345-354."""
+        self._alloc()
+        return (self.node_memories.data.clone(), self.node_last_updated_times.data.clone(),
+                (self.msg.clone(), self.msg_time.clone(), self.has_msg.clone()))
+
+    def reload_memory_bank(self, backup_memory_bank: tuple):
+        """MemoryModel.py:356-366."""
+        self.node_memories.data, self.node_last_updated_times.data = backup_memory_bank[0].clone(), backup_memory_bank[1].clone()
+        self.msg, self.msg_time, self.has_msg = (x.clone() for x in backup_memory_bank[2])
+
+    def detach_memory_bank(self):
+        """MemoryModel.py:368-378: nothing to detach, the HIP path builds no autograd graph."""
+
+    def get_memories(self, node_ids: np.ndarray):
+        return self.node_memories[torch.from_numpy(np.asarray(node_ids))]
+
+
+class GRUMemoryUpdater(nn.Module):
+    """memory_updater.memory_updater = nn.GRUCell(message_dim, memory_dim) (MemoryModel.py:490-501); the memory bank is
+    registered under it too, as in the reference, so the state_dict keys coincide."""
+
+    def __init__(self, memory_bank: MemoryBank, message_dim: int, memory_dim: int):
+        super().__init__()
+        self.memory_bank = memory_bank
+        self.memory_updater = nn.GRUCell(input_size=message_dim, hidden_size=memory_dim)
+
+
+class GraphAttentionEmbedding(nn.Module):
+    """Parameters of MemoryModel.py:548-578."""
+
+    def __init__(self, node_feat_dim, edge_feat_dim, time_feat_dim, num_layers, num_heads, dropout, neighbor_sampler, time_encoder):
+        super().__init__()
+        self.neighbor_sampler = neighbor_sampler
+        self.time_encoder = time_encoder              # the SAME module as the model's (MemoryModel.py:567): shared state_dict entries
+        self.temporal_conv_layers = nn.ModuleList([MultiHeadAttention(node_feat_dim, edge_feat_dim, time_feat_dim, num_heads, dropout)
+                                                   for _ in range(num_layers)])
+        self.merge_layers = nn.ModuleList([MergeLayer(input_dim1=node_feat_dim + time_feat_dim, input_dim2=node_feat_dim,
+                                                      hidden_dim=node_feat_dim, output_dim=node_feat_dim) for _ in range(num_layers)])
+
+
+class MemoryModel(nn.Module):
+
+    def __init__(self, node_raw_features: np.ndarray, edge_raw_features: np.ndarray, neighbor_sampler: NeighborSampler,
+                 time_feat_dim: int, model_name: str = "TGN", num_layers: int = 2, num_heads: int = 2, dropout: float = 0.1,
+                 src_node_mean_time_shift: float = 0.0, src_node_std_time_shift: float = 1.0, dst_node_mean_time_shift_dst: float = 0.0,
+                 dst_node_std_time_shift: float = 1.0, device: str = "cpu"):
+        super().__init__()
+        if model_name in ("DyRep", "JODIE"):
+            raise NotImplementedError(f"model_name {model_name} is not built on the HIP path (BASELINE config 5 is TGN)")
+        if model_name != "TGN":
+            raise ValueError(f"Not implemented error for model_name {model_name}!")           # MemoryModel.py:63
+        self.node_raw_features = torch.from_numpy(np.ascontiguousarray(node_raw_features, dtype=np.float32)).to(device)
+        self.edge_raw_features = torch.from_numpy(np.ascontiguousarray(edge_raw_features, dtype=np.float32)).to(device)
+        self.node_feat_dim, self.edge_feat_dim = self.node_raw_features.shape[1], self.edge_raw_features.shape[1]
+        self.time_feat_dim, self.num_layers, self.num_heads, self.dropout, self.device = time_feat_dim, num_layers, num_heads, dropout, device
+        self.model_name = model_name
+        self.num_nodes = self.node_raw_features.shape[0]
+        self.memory_dim = self.node_feat_dim
+        self.message_dim = self.memory_dim + self.memory_dim + self.time_feat_dim + self.edge_feat_dim
+        self.time_encoder = TimeEncoder(time_dim=time_feat_dim)
+        self.memory_bank = MemoryBank(self.num_nodes, self.memory_dim, self.message_dim)
+        self.memory_updater = GRUMemoryUpdater(self.memory_bank, self.message_dim, self.memory_dim)
+        self.embedding_module = GraphAttentionEmbedding(self.node_feat_dim, self.edge_feat_dim, self.time_feat_dim, num_layers, num_heads,
+                                                        dropout, neighbor_sampler, self.time_encoder)
+        self._lib = _capi.load()
+        self._workspace: Dict[tuple, torch.Tensor] = {}
+
+    def set_neighbor_sampler(self, neighbor_sampler: NeighborSampler):
+        """MemoryModel.py:253-263."""
+        self.embedding_module.neighbor_sampler = neighbor_sampler
+        if neighbor_sampler.sample_neighbor_strategy in ["uniform", "time_interval_aware"]:
+            assert neighbor_sampler.seed is not None
+            neighbor_sampler.reset_random_state()
+
+    def compute_src_dst_node_temporal_embeddings(self, src_node_ids, dst_node_ids, node_interact_times, edge_ids,
+                                                 edges_are_positive: bool = True, num_neighbors: int = 20) -> Tuple[torch.Tensor, torch.Tensor]:
+        """MemoryModel.py:87-168 (TGN).  Positive calls mutate the memory bank: issue batches in chronological order."""
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("training-mode forward / backward through the HIP path is not built yet (SURVEY.md §8f-1)")
+        sampler = self.embedding_module.neighbor_sampler
+        sampler._require_recent()
+        dev = self.memory_bank.node_memories.device
+        if dev.type != "cuda":
+            raise _capi.DygnnError("dyglib_amd.MemoryModel runs on an MI355X only; there is no CPU fallback")
+        if self.node_raw_features.device != dev:
+            self.node_raw_features, self.edge_raw_features = self.node_raw_features.to(dev), self.edge_raw_features.to(dev)
+        self.memory_bank._alloc()
+        to_dev = lambda x, dt: (x.to(device=dev, dtype=dt).contiguous() if isinstance(x, torch.Tensor)
+                                else torch.from_numpy(np.ascontiguousarray(x, dtype={torch.int64: np.int64, torch.float64: np.float64}[dt])).to(dev))
+        src, dst, tms = to_dev(src_node_ids, torch.int64), to_dev(dst_node_ids, torch.int64), to_dev(node_interact_times, torch.float64)
+        B = src.numel()
+        assert dst.numel() == B and tms.numel() == B
+        if edges_are_positive:
+            assert edge_ids is not None                                                        # MemoryModel.py:140
+        eids = to_dev(edge_ids, torch.int64) if edge_ids is not None else None
+        out_src = torch.empty((B, self.node_feat_dim), dtype=torch.float32, device=dev)
+        out_dst = torch.empty_like(out_src)
+        if B == 0:
+            return out_src, out_dst
+        cfg = _capi.TgatConfig(self.node_feat_dim, self.edge_feat_dim, self.time_feat_dim, self.num_layers, self.num_heads, int(num_neighbors))
+        w = _capi.TgatWeights()
+        w.time_w, w.time_b = self.time_encoder.w.weight.data_ptr(), self.time_encoder.w.bias.data_ptr()
+        em = self.embedding_module
+        for l in range(self.num_layers):
+            a, m, L = em.temporal_conv_layers[l], em.merge_layers[l], w.layers[l]
+            L.query_w, L.key_w, L.value_w = a.query_projection.weight.data_ptr(), a.key_projection.weight.data_ptr(), a.value_projection.weight.data_ptr()
+            L.ln_w, L.ln_b = a.layer_norm.weight.data_ptr(), a.layer_norm.bias.data_ptr()
+            L.res_w, L.res_b = a.residual_fc.weight.data_ptr(), a.residual_fc.bias.data_ptr()
+            L.fc1_w, L.fc1_b, L.fc2_w, L.fc2_b = m.fc1.weight.data_ptr(), m.fc1.bias.data_ptr(), m.fc2.weight.data_ptr(), m.fc2.bias.data_ptr()
+        cell = self.memory_updater.memory_updater
+        gru = _capi.GruWeights(cell.weight_ih.data_ptr(), cell.weight_hh.data_ptr(), cell.bias_ih.data_ptr(), cell.bias_hh.data_ptr())
+        mb = self.memory_bank
+        st = _capi.TgnState(self.num_nodes, mb.node_memories.data_ptr(), mb.node_last_updated_times.data_ptr(), mb.msg.data_ptr(),
+                            mb.msg_time.data_ptr(), mb.has_msg.data_ptr())
+        nbytes = self._lib.dygnn_tgn_workspace_bytes(C.byref(cfg), self.num_nodes, B)
+        if nbytes == 0:
+            _capi.check(-1)
+        key = (B, int(num_neighbors), torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._workspace.get(key)
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            if len(self._workspace) > 8:
+                self._workspace.clear()
+            ws = self._workspace[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _capi.check(self._lib.dygnn_tgn_forward(C.byref(cfg), C.byref(w), C.byref(gru), sampler.csr.on_device(dev),
+                                                self.node_raw_features.data_ptr(), self.edge_raw_features.data_ptr(), C.byref(st),
+                                                src.data_ptr(), dst.data_ptr(), tms.data_ptr(), eids.data_ptr() if eids is not None else None,
+                                                B, 1 if edges_are_positive else 0, out_src.data_ptr(), out_dst.data_ptr(),
+                                                ws.data_ptr(), ws.numel(), _capi.current_stream_ptr()))
+        return out_src, out_dst

@@ -248,3 +248,35 @@ def make_tgat_params(seed: int, node_feat_dim: int = NODE_FEAT_DIM, edge_feat_di
             val = rs.uniform(-1, 1, size=shape) / np.sqrt(fan_in)
         out[key] = np.ascontiguousarray(val, dtype=np.float32)
     return out
+
+
+def tgn_param_shapes(num_nodes: int, node_feat_dim: int = NODE_FEAT_DIM, edge_feat_dim: int = NODE_FEAT_DIM, time_feat_dim: int = 100,
+                     num_layers: int = 1) -> Dict[str, Tuple[int, ...]]:
+    """state_dict of the reference MemoryModel('TGN') (models/MemoryModel.py:43-74): the memory bank is registered twice
+    (memory_bank.* and memory_updater.memory_bank.*, same tensors)."""
+    Fn = node_feat_dim
+    Dm = 2 * Fn + time_feat_dim + edge_feat_dim
+    shapes: Dict[str, Tuple[int, ...]] = {"time_encoder.w.weight": (time_feat_dim, 1), "time_encoder.w.bias": (time_feat_dim,),
+                                          "memory_bank.node_memories": (num_nodes, Fn), "memory_bank.node_last_updated_times": (num_nodes,),
+                                          "memory_updater.memory_bank.node_memories": (num_nodes, Fn),
+                                          "memory_updater.memory_bank.node_last_updated_times": (num_nodes,),
+                                          "memory_updater.memory_updater.weight_ih": (3 * Fn, Dm), "memory_updater.memory_updater.weight_hh": (3 * Fn, Fn),
+                                          "memory_updater.memory_updater.bias_ih": (3 * Fn,), "memory_updater.memory_updater.bias_hh": (3 * Fn,)}
+    for k, v in tgat_param_shapes(node_feat_dim, edge_feat_dim, time_feat_dim, num_layers).items():
+        shapes["embedding_module." + k] = v          # includes embedding_module.time_encoder.* (the shared module)
+    return shapes
+
+
+def make_tgn_params(seed: int, num_nodes: int, num_layers: int = 1) -> Dict[str, np.ndarray]:
+    """Trainable TGN parameters (the memory bank starts at zero and is not part of this set)."""
+    rs = np.random.RandomState(seed)
+    out = {("embedding_module." + k if not k.startswith("time_encoder") else k): v for k, v in make_tgat_params(seed, num_layers=num_layers).items()}
+    for k in ("time_encoder.w.weight", "time_encoder.w.bias"):
+        out["embedding_module." + k] = out[k]        # shared module: both names, same values
+    Fn, Dm = NODE_FEAT_DIM, 2 * NODE_FEAT_DIM + 100 + NODE_FEAT_DIM
+    b = 1.0 / np.sqrt(Fn)
+    out["memory_updater.memory_updater.weight_ih"] = rs.uniform(-b, b, (3 * Fn, Dm)).astype(np.float32)
+    out["memory_updater.memory_updater.weight_hh"] = rs.uniform(-b, b, (3 * Fn, Fn)).astype(np.float32)
+    out["memory_updater.memory_updater.bias_ih"] = rs.uniform(-b, b, (3 * Fn,)).astype(np.float32)
+    out["memory_updater.memory_updater.bias_hh"] = rs.uniform(-b, b, (3 * Fn,)).astype(np.float32)
+    return out

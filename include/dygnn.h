@@ -201,6 +201,36 @@ int dygnn_tgat_forward(const dygnn_tgat_config* cfg_host, const dygnn_tgat_weigh
                        const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
                        float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * TGN: MemoryModel.compute_src_dst_node_temporal_embeddings with model_name == 'TGN'
+ * (models/MemoryModel.py:87-168): GRU memory update from the last pending raw message of every node
+ * (MessageAggregator :267-300, GRUMemoryUpdater :490-501 = nn.GRUCell(2F_n+F_t+F_e, F_n)), temporal graph
+ * attention over (memory + raw) node features (GraphAttentionEmbedding :548-664, same layer as TGAT), and —
+ * for positive edges — memory persistence + new raw messages (:142-161, :212-251).
+ * State lives in caller-owned device buffers and is MUTATED by positive calls; batches must be issued in
+ * chronological order on one stream (the reference's strict batch-sequential semantics).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dygnn_gru_weights {          /* memory_updater.memory_updater.{weight_ih,weight_hh,bias_ih,bias_hh}           */
+    const float *weight_ih, *weight_hh;     /* [3F_n, 2F_n+F_t+F_e], [3F_n, F_n]   (gate order r | z | n, nn.GRUCell)         */
+    const float *bias_ih, *bias_hh;         /* [3F_n], [3F_n]                                                                  */
+} dygnn_gru_weights;
+
+typedef struct dygnn_tgn_state {
+    int64_t  num_nodes;                     /* rows of node_raw_features (max node id + 1)                                     */
+    float*   memory;                        /* [N, F_n]  memory_bank.node_memories                                             */
+    float*   last_update;                   /* [N]       memory_bank.node_last_updated_times (float32)                         */
+    float*   msg;                           /* [N, 2F_n+F_t+F_e]  last pending raw message per node                            */
+    double*  msg_time;                      /* [N]       its interaction time                                                  */
+    int32_t* has_msg;                       /* [N]       1 while a message is pending (list non-empty, MemoryModel.py:284)     */
+} dygnn_tgn_state;
+
+size_t dygnn_tgn_workspace_bytes(const dygnn_tgat_config* cfg_host, int64_t num_nodes, int64_t batch);
+int dygnn_tgn_forward(const dygnn_tgat_config* cfg_host, const dygnn_tgat_weights* w_host, const dygnn_gru_weights* gru_host,
+                      const dygnn_csr* csr_host, const float* node_feat, const float* edge_feat, const dygnn_tgn_state* state_host,
+                      const int64_t* src, const int64_t* dst, const double* times, const int64_t* edge_ids /* NULL if !positive */,
+                      int64_t batch, int32_t edges_are_positive, float* out_src, float* out_dst,
+                      void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
+
 /* Caller-side link predictor, fused: sigmoid(MergeLayer(a,b)) with
  * MergeLayer = fc2(relu(fc1(cat(a,b)))) (models/modules.py:57-68; evaluate_models_utils.py:140-141).
  * a,b [n,dim]; fc1 [hidden, 2*dim]; fc2 [1,hidden]; out [n]. */

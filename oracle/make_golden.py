@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 from models.DyGFormer import DyGFormer as RefDyGFormer          # noqa: E402  (reference)
 from models.modules import MergeLayer as RefMergeLayer          # noqa: E402  (reference)
 from models.TGAT import TGAT as RefTGAT                         # noqa: E402  (reference)
+from models.MemoryModel import MemoryModel as RefMemoryModel    # noqa: E402  (reference)
 from utils.DataLoader import Data as RefData                    # noqa: E402  (reference)
 from utils.utils import get_neighbor_sampler as ref_get_neighbor_sampler  # noqa: E402  (reference)
 
@@ -109,11 +110,47 @@ def run_tgat_case(name: str) -> dict:
             "torch_version": np.array(torch.__version__)}
 
 
+def run_tgn_case(name: str) -> dict:
+    c = gc.build_tgn_case(name)
+    d, cfg = c["data"], c["tgn_cfg"]
+    # the sampler must only know interactions... the reference evaluates with the full graph sampler; so do we
+    ref_data = RefData(d.src_node_ids, d.dst_node_ids, d.node_interact_times, d.edge_ids, d.labels)
+    sampler = ref_get_neighbor_sampler(ref_data, sample_neighbor_strategy="recent", seed=1)
+    model = RefMemoryModel(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"], model_name="TGN",
+                           num_layers=cfg["num_layers"], num_heads=cfg["num_heads"], dropout=0.1, device="cpu")
+    sd = model.state_dict()
+    for k, v in c["tgn_params"].items():
+        assert k in sd and tuple(sd[k].shape) == v.shape, k
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    model.memory_bank.__init_memory_bank__()
+    out = {}
+    with torch.no_grad():
+        for i, b in enumerate(c["tgn_batches"]):
+            ns, nd = model.compute_src_dst_node_temporal_embeddings(b["src"], b["neg"], b["t"], edge_ids=None, edges_are_positive=False,
+                                                                    num_neighbors=cfg["num_neighbors"])
+            ps, pd = model.compute_src_dst_node_temporal_embeddings(b["src"], b["dst"], b["t"], edge_ids=b["eid"], edges_are_positive=True,
+                                                                    num_neighbors=cfg["num_neighbors"])
+            out[f"b{i}_neg_src"], out[f"b{i}_neg_dst"], out[f"b{i}_pos_src"], out[f"b{i}_pos_dst"] = ns.numpy(), nd.numpy(), ps.numpy(), pd.numpy()
+    out["final_memory"] = model.memory_bank.node_memories.data.numpy().copy()
+    out["final_last_update"] = model.memory_bank.node_last_updated_times.data.numpy().copy()
+    out["state_dict_keys"] = np.array(sorted(model.state_dict().keys()))
+    out["torch_version"] = np.array(torch.__version__)
+    return out
+
+
 def main():
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(8)
-    names = sys.argv[1:] or (list(gc.CASES) + list(gc.TGAT_CASES))
+    names = sys.argv[1:] or (list(gc.CASES) + list(gc.TGAT_CASES) + list(gc.TGN_CASES))
     for name in names:
+        if name in gc.TGN_CASES:
+            out = run_tgn_case(name)
+            path = os.path.join(gc.GOLDEN_DIR, name + ".npz")
+            np.savez_compressed(path, **out)
+            print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+            continue
         if name in gc.TGAT_CASES:
             out = run_tgat_case(name)
             path = os.path.join(gc.GOLDEN_DIR, name + ".npz")

@@ -44,6 +44,13 @@ TGAT_CASES = {
     "tgat_hub_l1_k10": dict(graph="hub_p4_l48", num_layers=1, num_neighbors=10, param_seed=203),
 }
 
+# TGN (BASELINE config 5): a chronological run of batches from interaction 0; per batch the negative call then the
+# positive call (evaluate_models_utils.py:93-113).  (graph case, layers, k, param seed, batch size, number of batches)
+TGN_CASES = {
+    "tgn_bip_l1_k10": dict(graph="bip_p2_l64", num_layers=1, num_neighbors=10, param_seed=301, batch=40, n_batches=6),
+    "tgn_gen_l2_k4": dict(graph="gen_p1_l32", num_layers=2, num_neighbors=4, param_seed=302, batch=25, n_batches=5),
+}
+
 TAP_ROWS = 3          # intermediates are stored for the first TAP_ROWS rows only
 SAMPLER_KS = (1, 10, 20)
 
@@ -92,4 +99,23 @@ def build_tgat_case(name: str):
     c = build_case(r["graph"])
     c["tgat_params"] = syn.make_tgat_params(r["param_seed"], num_layers=r["num_layers"])
     c["tgat_cfg"] = dict(num_layers=r["num_layers"], num_neighbors=r["num_neighbors"], num_heads=2, time_feat_dim=100)
+    return c
+
+
+def build_tgn_case(name: str):
+    r = TGN_CASES[name]
+    c = build_case(r["graph"])
+    d = c["data"]
+    n_nodes = c["node_feat"].shape[0]
+    c["tgn_params"] = syn.make_tgn_params(r["param_seed"], n_nodes, num_layers=r["num_layers"])
+    c["tgn_cfg"] = dict(num_layers=r["num_layers"], num_neighbors=r["num_neighbors"], num_heads=2, time_feat_dim=100)
+    # a bipartite graph's node features are all zero: give TGN something to add to the memory
+    c["node_feat"] = c["node_feat"].copy()
+    c["node_feat"][1:] = 0.5 * np.random.RandomState(r["param_seed"] + 7).standard_normal(c["node_feat"][1:].shape).astype(np.float32)
+    B, nb = r["batch"], r["n_batches"]
+    rs = np.random.RandomState(r["param_seed"] + 9)
+    uniq = np.unique(d.dst_node_ids)
+    c["tgn_batches"] = [dict(src=d.src_node_ids[i * B:(i + 1) * B], dst=d.dst_node_ids[i * B:(i + 1) * B],
+                             t=d.node_interact_times[i * B:(i + 1) * B], eid=d.edge_ids[i * B:(i + 1) * B],
+                             neg=syn.random_negative_dst(rs, uniq, B)) for i in range(nb)]
     return c

@@ -1,0 +1,98 @@
+"""TGN (BASELINE config 5): a chronological run of batches (negative call, then positive call that updates the memory
+bank) — oracle vs reference-generated golden vectors (CPU), HIP path through the C ABI vs golden (GPU), including the
+final memory table."""
+import numpy as np
+import pytest
+import torch
+
+from dyglib_amd import synthetic as syn
+from oracle import dygformer_oracle as orc
+from oracle import tgn_oracle as tn
+from tests import golden_cases as gc
+
+TOL = 1e-4
+
+
+def close(got, want, what=""):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape and np.isfinite(got).all(), what
+    atol = TOL * max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max())
+    assert err <= atol, f"{what}: max abs err {err:.3e} > {atol:.3e}"
+
+
+@pytest.fixture(scope="module", params=list(gc.TGN_CASES))
+def case(request):
+    c = gc.build_tgn_case(request.param)
+    return request.param, c, gc.load_golden(request.param)
+
+
+def test_oracle_matches_reference_golden(case):
+    name, c, g = case
+    d, cfg = c["data"], c["tgn_cfg"]
+    adj = orc.OracleAdjacency(d.src_node_ids, d.dst_node_ids, d.edge_ids, d.node_interact_times)
+    st = tn.TgnState(c["node_feat"].shape[0], 172)
+    for i, b in enumerate(c["tgn_batches"]):
+        ns, nd = tn.tgn_forward(c["tgn_params"], c["node_feat"], c["edge_feat"], adj, st, b["src"], b["neg"], b["t"], None, False,
+                                cfg["num_layers"], cfg["num_neighbors"], cfg["num_heads"])
+        ps, pd = tn.tgn_forward(c["tgn_params"], c["node_feat"], c["edge_feat"], adj, st, b["src"], b["dst"], b["t"], b["eid"], True,
+                                cfg["num_layers"], cfg["num_neighbors"], cfg["num_heads"])
+        close(nd.numpy(), g[f"b{i}_neg_dst"], f"{name} batch {i} neg dst")
+        close(ps.numpy(), g[f"b{i}_pos_src"], f"{name} batch {i} pos src")
+        close(pd.numpy(), g[f"b{i}_pos_dst"], f"{name} batch {i} pos dst")
+    close(st.M.numpy(), g["final_memory"], name + " memory")
+    close(st.U.numpy(), g["final_last_update"], name + " last update")
+
+
+def test_state_dict_keys_match_reference(case):
+    from dyglib_amd import MemoryModel, NeighborSampler
+    from dyglib_amd.temporal_csr import TemporalCSR
+    name, c, g = case
+    d, cfg = c["data"], c["tgn_cfg"]
+    sampler = NeighborSampler(None, "recent", seed=0, csr=TemporalCSR.from_interactions(
+        d.src_node_ids, d.dst_node_ids, d.edge_ids, d.node_interact_times), device="cpu")
+    m = MemoryModel(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=100, model_name="TGN", num_layers=cfg["num_layers"],
+                    num_heads=2, dropout=0.1, device="cpu")
+    assert sorted(m.state_dict().keys()) == g["state_dict_keys"].tolist()
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == syn.tgn_param_shapes(c["node_feat"].shape[0], num_layers=cfg["num_layers"])
+    with pytest.raises(NotImplementedError):
+        MemoryModel(c["node_feat"], c["edge_feat"], sampler, 100, model_name="JODIE")
+    with pytest.raises(ValueError):
+        MemoryModel(c["node_feat"], c["edge_feat"], sampler, 100, model_name="bogus")
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden(case):
+    from dyglib_amd import MemoryModel, get_neighbor_sampler
+    name, c, g = case
+    d, cfg = c["data"], c["tgn_cfg"]
+    dev = "cuda:0"
+    sampler = get_neighbor_sampler(d, "recent", seed=1, device=dev)
+    m = MemoryModel(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=100, model_name="TGN", num_layers=cfg["num_layers"],
+                    num_heads=2, dropout=0.1, device=dev)
+    sd = m.state_dict()
+    sd.update({k: torch.from_numpy(v) for k, v in c["tgn_params"].items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    m.memory_bank.__init_memory_bank__()
+    k = cfg["num_neighbors"]
+    backup = None
+    with torch.no_grad():
+        for i, b in enumerate(c["tgn_batches"]):
+            if i == 2:
+                backup = m.memory_bank.backup_memory_bank()
+            ns, nd = m.compute_src_dst_node_temporal_embeddings(b["src"], b["neg"], b["t"], edge_ids=None, edges_are_positive=False, num_neighbors=k)
+            ps, pd = m.compute_src_dst_node_temporal_embeddings(b["src"], b["dst"], b["t"], edge_ids=b["eid"], edges_are_positive=True, num_neighbors=k)
+            close(ns.cpu().numpy(), g[f"b{i}_neg_src"], f"{name} batch {i} neg src")
+            close(nd.cpu().numpy(), g[f"b{i}_neg_dst"], f"{name} batch {i} neg dst")
+            close(ps.cpu().numpy(), g[f"b{i}_pos_src"], f"{name} batch {i} pos src")
+            close(pd.cpu().numpy(), g[f"b{i}_pos_dst"], f"{name} batch {i} pos dst")
+        close(m.memory_bank.node_memories.data.cpu().numpy(), g["final_memory"], name + " memory")
+        close(m.memory_bank.node_last_updated_times.data.cpu().numpy(), g["final_last_update"], name + " last update")
+        # reload the backup taken before batch 2 and replay: same results (backup/reload round trip, MemoryModel.py:345-366)
+        m.memory_bank.reload_memory_bank(backup)
+        b = c["tgn_batches"][2]
+        ps, pd = m.compute_src_dst_node_temporal_embeddings(b["src"], b["dst"], b["t"], edge_ids=b["eid"], edges_are_positive=True, num_neighbors=k)
+        close(ps.cpu().numpy(), g["b2_pos_src"], name + " replay")
+        with pytest.raises(AssertionError):
+            m.compute_src_dst_node_temporal_embeddings(b["src"], b["dst"], b["t"], edge_ids=None, edges_are_positive=True, num_neighbors=k)
