@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Secondary benchmark (BASELINE config 5): TGN link-prediction forward on a MOOC-shaped synthetic graph
+(7,047 + 97 nodes, 411,749 edges, 4 non-zero edge-feature columns), k = 10, 1 layer, batch 200, batches strictly in
+chronological order from interaction 0: negative call + positive call (memory update) + MergeLayer+sigmoid per step.
+TGN does not shard: "replicas only" (SURVEY.md §8e)."""
+import argparse, json, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dyglib_amd import MemoryModel, MergeLayer, get_neighbor_sampler, synthetic as syn
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=100); ap.add_argument("--warmup", type=int, default=10); ap.add_argument("--cpu-steps", type=int, default=10)
+args = ap.parse_args()
+dev, B, K = "cuda:0", 200, 10
+data, nf, ef = syn.make_bipartite_graph(7047, 97, 411749, seed=0, edge_feat_kind="sparse4")
+params, mparams = syn.make_tgn_params(0, nf.shape[0], num_layers=1), syn.make_merge_layer_params(1000)
+sampler = get_neighbor_sampler(data, "recent", seed=1, device=dev)
+model = MemoryModel(nf, ef, sampler, 100, model_name="TGN", num_layers=1, num_heads=2, dropout=0.1, device=dev)
+sd = model.state_dict(); sd.update({k: torch.from_numpy(v) for k, v in params.items()}); model.load_state_dict(sd)
+merge = MergeLayer(172, 172, 172, 1); merge.load_state_dict({k: torch.from_numpy(v) for k, v in mparams.items()})
+model, merge = model.to(dev).eval(), merge.to(dev).eval()
+rs = np.random.RandomState(2); ud = np.unique(data.dst_node_ids)
+n = args.steps + args.warmup
+host = [(data.src_node_ids[i * B:(i + 1) * B], data.dst_node_ids[i * B:(i + 1) * B], syn.random_negative_dst(rs, ud, B),
+         data.node_interact_times[i * B:(i + 1) * B], data.edge_ids[i * B:(i + 1) * B]) for i in range(n)]
+batches = [tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in b) for b in host]
+def step(i):
+    s, d, ng, t, e = batches[i]
+    with torch.no_grad():
+        a, b_ = model.compute_src_dst_node_temporal_embeddings(s, ng, t, edge_ids=None, edges_are_positive=False, num_neighbors=K)
+        c, f = model.compute_src_dst_node_temporal_embeddings(s, d, t, edge_ids=e, edges_are_positive=True, num_neighbors=K)
+        return merge.link_probabilities(c, f), merge.link_probabilities(a, b_)
+model.memory_bank.__init_memory_bank__()
+for i in range(args.warmup): step(i)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(args.steps): step(args.warmup + i)
+torch.cuda.synchronize(); el = time.perf_counter() - t0
+out = {"metric": "edges/sec (link-prediction fwd) TGN MOOC-shaped", "value": round(args.steps * B / el, 1), "unit": "edges/s", "n_gpus": 1,
+       "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "dtype": "f32", "data": "synthetic", "scaling": "replicas only",
+       "config": {"workload": "TGN link-prediction forward, synthetic MOOC-shaped graph (7047+97 nodes, 411749 edges), k=10, 1 layer, batch=200, sequential batches"}}
+if args.cpu_steps > 0:
+    from oracle import dygformer_oracle as orc, tgn_oracle as tn
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    nft, eft = torch.from_numpy(nf), torch.from_numpy(ef)
+    tp = {k: torch.from_numpy(v) for k, v in params.items()}
+    st = tn.TgnState(nf.shape[0], 172)
+    t0 = time.perf_counter()
+    for i in range(args.cpu_steps):
+        s, d, ng, t, e = host[i]
+        tn.tgn_forward(tp, nft, eft, adj, st, s, ng, t, None, False, 1, K, 2); tn.tgn_forward(tp, nft, eft, adj, st, s, d, t, e, True, 1, K, 2)
+    cel = time.perf_counter() - t0
+    out["cpu_baseline"] = {"value": round(args.cpu_steps * B / cel, 1), "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+                           "sample": f"the first {args.cpu_steps} steps ({cel:.1f} s), oracle/tgn_oracle.py"}
+print(json.dumps(out))
