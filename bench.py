@@ -57,7 +57,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="wikipedia", choices=list(WORKLOADS))
-    ap.add_argument("--impl", type=int, default=0, help="0 auto, 1 generic kernels, 2 fused kernel")
+    ap.add_argument("--impl", type=int, default=0, help="0 auto, 1 generic kernels, 2 fused kernel (wave-pair), 3 fused kernel (token-owner)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the launches are issued on (round-robin)")
     ap.add_argument("--fuse-steps", type=int, default=8,
                     help="steps per launch: the positive and negative calls of F consecutive steps (2F independently "
@@ -191,7 +191,7 @@ def main():
         import glob
         tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))[-1]
         tj = json.load(open(tf))
-        if args.workload == "wikipedia" and args.impl in (0, 2):
+        if args.workload == "wikipedia" and args.impl in (0, 2, 3):
             traffic = tj["hbm_bytes_per_pair"] * 2 * steps_per_launch * B
     except Exception:
         traffic = None
@@ -207,7 +207,7 @@ def main():
                                f"2 layers, 2 heads, C=50; pos+neg calls + MergeLayer+sigmoid per step",
                    "batch": B, "max_input_sequence_length": L, "patch_size": P,
                    "parallelism": f"{world} x edge-batch shard, graph+weights replicated, metric all-reduce over RCCL",
-                   "impl": {0: "auto", 1: "generic", 2: "fused"}[args.impl], "streams": len(streams),
+                   "impl": {0: "auto", 1: "generic", 2: "fused", 3: "fused3"}[args.impl], "streams": len(streams),
                    "steps_per_launch": F},
         "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,

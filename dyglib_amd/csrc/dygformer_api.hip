@@ -16,6 +16,14 @@ int forward_fused(const Dims&, const PackedLayout&, const dygnn_dygformer_weight
                   int64_t B, int64_t G, float* out_src, float* out_dst, char* ws, const WorkspaceLayout&, const dygnn_dygformer_taps*,
                   hipStream_t);
 
+// dygformer_fused3.hip
+bool fused3_supported(const Dims&);
+int pack_fused3(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, float* packed, hipStream_t);
+int forward_fused3(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, const float* packed, const dygnn_csr*,
+                   const float* node_feat, const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times,
+                   int64_t B, int64_t G, float* out_src, float* out_dst, char* ws, const WorkspaceLayout&, const dygnn_dygformer_taps*,
+                   hipStream_t);
+
 static int check_weights(const Dims& d, const dygnn_dygformer_weights* w) {
     DYGNN_REQUIRE(w != nullptr, "weights is NULL");
     const void* p[] = {w->time_w, w->time_b, w->cooc_w0, w->cooc_b0, w->cooc_w1, w->cooc_b1, w->proj_node_w, w->proj_node_b,
@@ -91,6 +99,8 @@ extern "C" int dygnn_dygformer_pack(const dygnn_dygformer_config* cfg, const dyg
     if (int rc = pack_generic(d, pl, w, static_cast<float*>(packed), as_stream(stream))) return rc;
     if (fused_supported(d))
         if (int rc = pack_fused(d, pl, w, static_cast<float*>(packed), as_stream(stream))) return rc;
+    if (fused3_supported(d))
+        if (int rc = pack_fused3(d, pl, w, static_cast<float*>(packed), as_stream(stream))) return rc;
     return DYGNN_OK;
 }
 
@@ -108,7 +118,7 @@ extern "C" int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg, const 
     if (group_size == 0 || group_size > batch) group_size = batch;      // one group = the reference's single call
     DYGNN_REQUIRE(packed && node_feat && edge_feat, "forward: null table / packed pointer");
     DYGNN_REQUIRE(batch == 0 || (src && dst && times && out_src && out_dst && workspace), "forward: null pointer");
-    DYGNN_REQUIRE(impl >= 0 && impl <= 2, "forward: impl must be 0 (auto), 1 (generic) or 2 (fused)");
+    DYGNN_REQUIRE(impl >= 0 && impl <= 3, "forward: impl must be 0 (auto), 1 (generic), 2 (fused, wave-pair layout) or 3 (fused, token-owner layout)");
     if (batch == 0) return DYGNN_OK;
     const WorkspaceLayout wl = make_workspace_layout(d, batch);
     if (workspace_bytes < wl.total) {
@@ -121,8 +131,14 @@ extern "C" int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg, const 
         set_error("forward: fused kernel does not support this shape (D=%d H=%d tokens<=%d)", d.D, d.H, d.Tmax);
         return DYGNN_E_UNSUPPORTED;
     }
-    const bool use_fused = (impl == 2) || (impl == 0 && can_fuse);
-    auto fn = use_fused ? forward_fused : forward_generic;
+    const bool can_fuse3 = fused3_supported(d);
+    if (impl == 3 && !can_fuse3) {
+        set_error("forward: token-owner fused kernel does not support this shape (D=%d H=%d tokens<=%d)", d.D, d.H, d.Tmax);
+        return DYGNN_E_UNSUPPORTED;
+    }
+    auto fn = forward_generic;
+    if (impl == 3) fn = forward_fused3;
+    else if (impl == 2 || (impl == 0 && can_fuse)) fn = forward_fused;
     return fn(d, pl, w, static_cast<const float*>(packed), csr, node_feat, edge_feat, src, dst, times, batch, group_size, out_src, out_dst,
               static_cast<char*>(workspace), wl, taps, as_stream(stream));
 }

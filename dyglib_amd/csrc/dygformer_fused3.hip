@@ -1,0 +1,916 @@
+// Fused DyGFormer forward for gfx950, "token-owner" layout (models/DyGFormer.py:68-194 end to end).
+//
+// One workgroup = 8 wave64 = 128 tokens: two (src,dst,t) pairs of <= 64 tokens (TPW = 4 token tiles per pair) or one
+// pair of <= 128 tokens (TPW = 8; BASELINE config 4, L=512 / P=8).  Wave w owns 16 tokens x ALL 200 channels:
+//   * the residual stream X^T (13 accumulator tiles = 52 VGPRs) never leaves the wave's registers;
+//   * LayerNorm is wave-local (register sums + two cross-lane adds) and its output IS the MFMA B operand of the
+//     QKV / FFN products — no LDS round trip, no partial-sum exchange between waves, no K-split;
+//   * Q^T, softmax(S)^T, O^T and gelu(H)^T feed the next product straight from accumulators (same layout trick
+//     as dygformer_fused.hip: an accumulator tile is the B operand of the product that sums over its rows).
+// Only K and V of ONE head at a time live in LDS ([128 tokens][100], 2 x 51.2 KB); heads run back to back.
+//
+// Weights: all 8 waves consume the SAME fragments in the SAME order, so the whole model is ONE linear stream of
+// 1-KiB MFMA-A fragments per kernel, brought on chip once per workgroup by LDS-DMA (global_load_lds, no VGPRs)
+// into a 52-fragment LDS ring and read with ds_read_b128.  (Measured in tools/v3_ubench.hip: weight fragments
+// loaded global->VGPR per wave hold the MFMA pipe at 66 %, LDS-DMA staged at 85 %, registers only 90 %.)
+// The ring protocol: stages of 13 fragments; after the step that finishes a stage every wave waits for its own
+// DMAs, passes one barrier, and issues its share of the stage four ahead.  Steps never straddle the ring end
+// (the packer inserts pad fragments with the same rule the consumer applies).
+#include <type_traits>
+#include <vector>
+
+#include "dygformer_layout.h"
+
+namespace dygnn {
+namespace v3 {
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+using i4 = __attribute__((ext_vector_type(4))) int;
+
+constexpr int kD = 200, kDP = 208, kNT = 13, kKC = 13, kHD = 100, kHid = 800, kC = 50;
+constexpr int kFrag = 256;            // floats per 16x16 fragment
+constexpr int kRing = 52;             // LDS ring, fragments
+constexpr int kStage = 13;            // DMA / barrier granularity, fragments
+constexpr int kTokWG = 128;           // tokens per workgroup
+constexpr int kKV = 100;              // K/V row stride (floats): 4*25 -> conflict-free b128 row reads and b32 column reads
+constexpr int kLdsK = 0;
+constexpr int kLdsV = kTokWG * kKV;                 // 12800
+constexpr int kLdsRing = 2 * kTokWG * kKV + 16;     // 16 floats of slack: tile 6 of the last row reads 12 floats past it
+constexpr int kLdsMisc = kLdsRing + kRing * kFrag;  // 38928 floats = 155,712 B
+constexpr int kMiscLn = 0;            // [4][208]: ln0 gamma, ln0 beta, ln1 gamma, ln1 beta
+constexpr int kMiscB1 = 4 * kDP;      // [800]
+constexpr int kMiscFloats = 4 * kDP + kHid;         // 1632
+constexpr int kLdsBytes = 160 * 1024;
+static_assert((kLdsMisc + kMiscFloats) * 4 <= kLdsBytes, "LDS budget");
+constexpr int kScratchFloats = 2 * kTokWG * kKV;    // prologue window arrays live in the K/V region
+
+__device__ __forceinline__ f4 mfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+template <int N>
+__device__ __forceinline__ void mma_group(f4* acc, const f4* a, const f4 b) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) acc[u] = mfma(a[u].x, b.x, acc[u]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) acc[u] = mfma(a[u].y, b.y, acc[u]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) acc[u] = mfma(a[u].z, b.z, acc[u]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) acc[u] = mfma(a[u].w, b.w, acc[u]);
+}
+__device__ __forceinline__ f4 ldg4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ f4 lds4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ f4 zero4() { return f4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ void dma_frag(const float* gsrc_lane, float* lds_dst_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+}
+
+// cos for the time encoder and erf for GELU: same functions as dygformer_fused.hip (see the derivations there)
+__device__ __forceinline__ float cos_time(float x) {
+    if (!(fabsf(x) <= 3.0e7f)) return cosf(x);
+    const float INV_HI = 0.15915493667125702f, INV_LO = 6.4206382432985265e-09f;
+    const float p = x * INV_HI;
+    const float e = fmaf(x, INV_HI, -p);
+    const float q = fmaf(x, INV_LO, e);
+    const float t = (p - rintf(p)) + q;
+    float u = fabsf(t);
+    u = u > 0.5f ? 1.0f - u : u;
+    const bool flip = u > 0.25f;
+    const float v = flip ? 0.5f - u : u;
+    const float z = v * v;
+    float r = fmaf(7.903536371318467f, z, -26.42625678337438f);
+    r = fmaf(r, z, 60.24464137187666f);
+    r = fmaf(r, z, -85.45681720669373f);
+    r = fmaf(r, z, 64.93939402266829f);
+    r = fmaf(r, z, -19.739208802178716f);
+    r = fmaf(r, z, 1.0f);
+    return flip ? -r : r;
+}
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __expf(-ax * ax);
+    return copysignf(fmaf(-p * t, e, 1.0f), x);
+}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f)); }
+
+struct LayerP {
+    const float* ln;      // [4][208]
+    const float* bqkv;    // [2 heads][q,k,v][7 tiles][16], rows >= 100 of a head are zero
+    const float *bo, *b1, *b2;   // [208], [800], [208]
+};
+
+struct Args {
+    const int64_t* indptr; const int32_t* nbr; const int32_t* eid; const double* ts;
+    const int64_t *src, *dst; const double* times;
+    const int32_t* hist_len; const int64_t* end_pos; const CallDims* cd;
+    const float *node_feat, *edge_feat, *time_w, *time_b, *lut;
+    const float* stream; int nstages;
+    const float* bias_x;          // [208] projection biases in model-dim order
+    LayerP layer[DYGNN_MAX_LAYERS];
+    const float *outT, *outb;     // output layer: transposed [200][Fn], bias [Fn]
+    float *out_src, *out_dst;
+    float* tap_enc; float* tap_layer[DYGNN_MAX_LAYERS];
+    unsigned long long* stamps;
+    int64_t B, G;
+    int Fn, Fe, Ft, P, L, NL, Tmax;
+    int nchunk[4];
+    float qscale;
+};
+
+// ---- the shared weight stream ---------------------------------------------------------------------------------
+struct WStream {
+    const float* gsrc;    // stream base + lane*4 (per lane)
+    float* ring;          // LDS ring (wave-uniform)
+    int wave, nstages;
+    int pos;              // ring slot of the next fragment
+    int instage;          // fragments consumed of the current stage
+    int issued;           // stages whose DMA this wave has issued
+    __device__ __forceinline__ void issue(int s) {
+        if (s < nstages) {
+            const float* srcp = gsrc + (size_t)s * (kStage * kFrag);
+            float* dst = ring + (s & 3) * (kStage * kFrag);
+            dma_frag(srcp + wave * kFrag, dst + wave * kFrag);
+            if (wave + 8 < kStage) dma_frag(srcp + (wave + 8) * kFrag, dst + (wave + 8) * kFrag);
+        }
+    }
+    __device__ __forceinline__ void open(const float* stream, float* ring_, int lane, int wave_, int nstages_) {
+        gsrc = stream + lane * 4; ring = ring_; wave = wave_; nstages = nstages_;
+        pos = 0; instage = 0; issued = 4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) issue(s);
+    }
+    // n fragments consumed (or skipped).  Crossing a stage boundary: wait for own DMAs, barrier (every wave is done with
+    // the finished stage, every stage issued before is now visible), then refill the freed ring quarter.
+    __device__ __forceinline__ void advance(int n) {
+        pos += n;
+        if (pos >= kRing) pos -= kRing;
+        instage += n;
+        if (instage >= kStage) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's LDS-DMA has landed before anyone passes the barrier
+            __syncthreads();
+            do { instage -= kStage; issue(issued); ++issued; } while (instage >= kStage);
+        }
+    }
+    __device__ __forceinline__ void fit(int n) { if (pos + n > kRing) advance(kRing - pos); }
+    __device__ __forceinline__ void align26() {
+        if (pos != 0 && pos != 26) advance(pos < 26 ? 26 - pos : kRing - pos);
+    }
+    // ring slot of the step after one of n fragments that starts at `pos` (same rule as advance + fit)
+    __device__ __forceinline__ int next_pos(int n, int n_next) const {
+        int p = pos + n;
+        if (p >= kRing) p -= kRing;
+        if (p + n_next > kRing) p = 0;
+        return p;
+    }
+};
+
+#ifdef DYGNN_STAMPS
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        if (a.stamps != nullptr && lane == 0 && blockIdx.x + 4 >= gridDim.x)                       \
+            a.stamps[((size_t)(blockIdx.x + 4 - gridDim.x) * 8 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+// LayerNorm of the register-resident X^T (two-pass, biased variance, eps 1e-5); gamma/beta from LDS
+__device__ __forceinline__ void layernorm(f4 (&xn)[kNT], const f4 (&x)[kNT], const float* gamma, const float* beta, int g) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) s += (x[i].x + x[i].y) + (x[i].z + x[i].w);     // rows 200..207 are exact zeros
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / kD);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) {
+        if (i < 12 || g < 2) {            // rows 200..207 (tile 12, g >= 2) are padding
+            const float d0 = x[i].x - mean, d1 = x[i].y - mean, d2 = x[i].z - mean, d3 = x[i].w - mean;
+            v += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    }
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    const float rstd = 1.0f / sqrtf(v * (1.0f / kD) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) {
+        const f4 gm = lds4(gamma + 16 * i + 4 * g), bt = lds4(beta + 16 * i + 4 * g);   // zero beyond 200
+        xn[i].x = (x[i].x - mean) * rstd * gm.x + bt.x;
+        xn[i].y = (x[i].y - mean) * rstd * gm.y + bt.y;
+        xn[i].z = (x[i].z - mean) * rstd * gm.z + bt.z;
+        xn[i].w = (x[i].w - mean) * rstd * gm.w + bt.w;
+    }
+}
+
+// acc[7] += W(7 tiles of one head's q, k or v) . xn : 13 stream steps of 7 fragments [k-chunk][tile]
+__device__ __forceinline__ void qkv_group(f4 (&acc)[7], const f4 (&xn)[kNT], WStream& ws, const float* ringl, bool active) {
+    f4 fa[2][7];
+    ws.fit(7);
+    if (active) {
+#pragma unroll
+        for (int u = 0; u < 7; ++u) fa[0][u] = lds4(ringl + (ws.pos + u) * kFrag);
+    }
+#pragma unroll
+    for (int kc = 0; kc < kKC; ++kc) {
+        const int cur = kc & 1;
+        if (active) {
+            if (kc + 1 < kKC) {
+                const int p1 = ws.next_pos(7, 7);
+#pragma unroll
+                for (int u = 0; u < 7; ++u) fa[cur ^ 1][u] = lds4(ringl + (p1 + u) * kFrag);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_group<7>(acc, fa[cur], xn[kc]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ws.advance(7);
+        if (kc + 1 < kKC) ws.fit(7);
+    }
+}
+
+template <int TPW>
+__device__ __forceinline__ void tap_store(const f4 (&x)[kNT], float* base, int64_t b, int Tmax, int T, int tt, int c, int g) {
+    if (base == nullptr) return;
+    const int tok = 16 * tt + c;
+    if (tok >= T) return;
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) {
+        const int n = 16 * i + 4 * g;
+        if (n < kD) *reinterpret_cast<f4*>(base + ((size_t)b * Tmax + tok) * kD + n) = x[i];
+    }
+}
+
+// ================================================================================================
+template <int TPW>
+__global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
+    constexpr int NP = 8 / TPW;                  // pairs per workgroup
+    constexpr int PT = 512 / NP;                 // threads per pair
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pi = wave / TPW, tt = wave % TPW;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t b = (int64_t)blockIdx.x * NP + pi;
+    const bool pair_ok = b < a.B;
+    const int ptid = tid - pi * PT;
+
+    STAMP(0);
+    CallDims cd{};
+    if (pair_ok) cd = a.cd[b / a.G];
+    const int Ss = cd.S_s, Sd = cd.S_d, Ts = cd.T_s, T = cd.T;
+    const int SsA = (Ss + 3) & ~3, SdA = (Sd + 3) & ~3, SA = SsA + SdA;
+    const bool active = 16 * tt < T;             // wave-uniform: this token tile holds real tokens
+    const int tokbase = pi * (16 * TPW);         // this pair's first K/V row
+
+    // ---- zero K, V, slack and misc once (rows of absent tokens are read as MFMA operands and must be finite)
+    for (int i = tid; i < kLdsRing / 4; i += 512) reinterpret_cast<f4*>(lds)[i] = zero4();
+    for (int i = tid; i < kMiscFloats / 4; i += 512) reinterpret_cast<f4*>(lds + kLdsMisc)[i] = zero4();
+    WStream ws;
+    ws.open(a.stream, lds + kLdsRing, lane, wave, a.nstages);      // the first four stages fly during the window phase
+    const float* ringl = lds + kLdsRing + lane * 4;
+    __syncthreads();
+
+    // ---- windows (pad_sequences, DyGFormer.py:228-245): per-pair arrays in the (still unused) K/V region.
+    // src positions at [0, Ss), dst positions at [SsA, SsA + Sd); alignment gaps hold id -1 (matches nothing).
+    int32_t* ids = reinterpret_cast<int32_t*>(lds) + pi * (kScratchFloats / NP);
+    int32_t* eids = ids + SA;
+    float* dts = reinterpret_cast<float*>(eids + SA);
+    int32_t* c0 = reinterpret_cast<int32_t*>(dts + SA);
+    int32_t* c1 = c0 + SA;
+    if (pair_ok) {
+        const double tq = a.times[b];
+        for (int p = ptid; p < SA; p += PT) {
+            const bool is_dst = p >= SsA;
+            const int j = is_dst ? p - SsA : p;
+            int32_t id = -1, e = 0;
+            float dt = 0.f;
+            if (j < (is_dst ? Sd : Ss)) {
+                const int64_t q = is_dst ? a.B + b : b;
+                const int32_t len = a.hist_len[q];
+                const int32_t m = len < a.L - 1 ? len : a.L - 1;
+                float tn = 0.f;
+                id = 0;
+                if (j == 0) {
+                    id = (int32_t)(is_dst ? a.dst[b] : a.src[b]); tn = (float)tq;
+                } else if (j <= m) {
+                    const int64_t pos = a.end_pos[q] - m + (j - 1);
+                    id = a.nbr[pos]; e = a.eid[pos]; tn = (float)a.ts[pos];
+                }
+                dt = (float)(tq - (double)tn);                      // DyGFormer.py:263
+            }
+            ids[p] = id; eids[p] = e; dts[p] = dt;
+        }
+    }
+    __syncthreads();
+    // ---- co-occurrence counts (DyGFormer.py:337-393): one thread per position, 4 ids per broadcast LDS read
+    if (pair_ok) {
+        for (int p = ptid; p < SA; p += PT) {
+            const int32_t v = ids[p];
+            int32_t cs = 0, cdn = 0;
+            for (int q = 0; q < SsA; q += 4) {
+                const i4 w = *reinterpret_cast<const i4*>(ids + q);
+                cs += (w.x == v) + (w.y == v) + (w.z == v) + (w.w == v);
+            }
+            for (int q = SsA; q < SA; q += 4) {
+                const i4 w = *reinterpret_cast<const i4*>(ids + q);
+                cdn += (w.x == v) + (w.y == v) + (w.z == v) + (w.w == v);
+            }
+            if (v <= 0) { cs = 0; cdn = 0; }       // padding node 0 (DyGFormer.py:389-391) and alignment gaps
+            c0[p] = cs; c1[p] = cdn;
+        }
+    }
+    __syncthreads();
+
+    STAMP(1);
+    // ---- resident residual stream X^T: 13 tiles (rows 16i+4g+r) x token c of tile tt
+    f4 x[kNT];
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) x[i] = ldg4(a.bias_x + 16 * i + 4 * g);
+
+    // ---- patch projection (DyGFormer.py:148-157): channel ch writes model rows 50ch..50ch+49 = tiles (50ch)/16 .. +3.
+    // One stream step = one 16-wide k-chunk x 4 tiles.  The B operand is gathered straight from the feature tables
+    // (two chunks ahead); (pp, f) = (patch position, feature) of this lane's k are advanced incrementally.
+    {
+        const int tok = 16 * tt + c;
+        const bool tv = tok < T;
+        const int pos0 = tv ? (tok < Ts ? tok * a.P : SsA + (tok - Ts) * a.P) : 0;
+        const int P = a.P;
+        struct Cursor { int pp, f; };
+        auto step_cursor = [](Cursor& cu, int F) { cu.f += 16; if (cu.f >= F) { cu.f -= F; ++cu.pp; } };
+        auto project = [&](auto LOCAL0, int nchunk, int F, auto bfn) {
+            constexpr int L0 = decltype(LOCAL0)::value;
+            Cursor cu{0, 4 * g};
+            f4 b0 = zero4(), b1 = zero4(), b2 = zero4();
+            if (active) {
+                b0 = bfn(cu); step_cursor(cu, F);
+                b1 = bfn(cu); step_cursor(cu, F);
+            }
+            for (int kc = 0; kc < nchunk; ++kc) {
+                if (active) {
+                    b2 = bfn(cu); step_cursor(cu, F);           // chunk kc+2 (zeros beyond the patch)
+                    f4 fa[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) fa[u] = lds4(ringl + (ws.pos + u) * kFrag);
+                    mma_group<4>(&x[L0], fa, b0);
+                    b0 = b1; b1 = b2;
+                }
+                ws.advance(4);                                  // 52 = 13 steps of 4: never straddles the ring end
+            }
+        };
+        auto gather = [&](const float* table, const int32_t* idx, int F) {
+            return [=](const Cursor& cu) -> f4 {
+                if (!tv || cu.pp >= P) return zero4();
+                int32_t r = idx[pos0 + cu.pp];
+                r = r < 0 ? 0 : r;
+                return ldg4(table + (size_t)r * F + cu.f);                                           // DyGFormer.py:259-261
+            };
+        };
+        auto timef = [&](const Cursor& cu) -> f4 {
+            if (!tv || cu.pp >= P || ids[pos0 + cu.pp] <= 0) return zero4();                         // DyGFormer.py:266
+            const float dt = dts[pos0 + cu.pp];
+            const f4 w = ldg4(a.time_w + cu.f), bb = ldg4(a.time_b + cu.f);
+            f4 r;
+            r.x = cos_time(fmaf(dt, w.x, bb.x)); r.y = cos_time(fmaf(dt, w.y, bb.y));
+            r.z = cos_time(fmaf(dt, w.z, bb.z)); r.w = cos_time(fmaf(dt, w.w, bb.w));
+            return r;
+        };
+        // co-occurrence features: k = 50*pp + j is not 4-aligned per position, so every element finds its own (pp, j);
+        // k/50 by multiply-shift (exact for k < 12000)
+        int kco = 4 * g;
+        auto coocf = [&](const Cursor&) -> f4 {
+            f4 r;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = kco + t;
+                const int pp = (k * 1311) >> 16;
+                float v = 0.f;
+                if (tv && pp < P) {
+                    const int j = k - pp * kC;
+                    v = a.lut[(size_t)c0[pos0 + pp] * kC + j] + a.lut[(size_t)c1[pos0 + pp] * kC + j];   // DyGFormer.py:409-411
+                }
+                r[t] = v;
+            }
+            kco += 16;
+            return r;
+        };
+        ws.fit(4);
+        project(std::integral_constant<int, 0>{}, a.nchunk[0], a.Fn, gather(a.node_feat, ids, a.Fn));
+        project(std::integral_constant<int, 3>{}, a.nchunk[1], a.Fe, gather(a.edge_feat, eids, a.Fe));
+        project(std::integral_constant<int, 6>{}, a.nchunk[2], a.Ft, timef);
+        project(std::integral_constant<int, 9>{}, a.nchunk[3], 1 << 30, coocf);
+    }
+    STAMP(2);
+    __syncthreads();     // everyone is done with the window arrays
+    for (int i = tid; i < kScratchFloats / 4; i += 512) reinterpret_cast<f4*>(lds)[i] = zero4();
+    tap_store<TPW>(x, a.tap_enc, b, a.Tmax, T, tt, c, g);
+
+    float* Kb = lds + kLdsK;
+    float* Vb = lds + kLdsV;
+    float* misc = lds + kLdsMisc;
+
+    for (int l = 0; l < a.NL; ++l) {
+        const LayerP& W = a.layer[l];
+        STAMP(3 + 8 * l);
+        __syncthreads();                 // previous layer is done with ln / b1 (and the re-zeroing above is complete)
+        for (int i = tid; i < 4 * kDP; i += 512) misc[kMiscLn + i] = W.ln[i];
+        for (int i = tid; i < kHid; i += 512) misc[kMiscB1 + i] = W.b1[i];
+        __syncthreads();
+
+        f4 xn[kNT];
+        if (active) layernorm(xn, x, misc + kMiscLn, misc + kMiscLn + kDP, g);
+        STAMP(4 + 8 * l);
+
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            // ================= Q, K, V of head h =================
+            f4 qa[7];
+            {
+                const float* bq = W.bqkv + (size_t)(h * 3 + 0) * 112 + 4 * g;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) qa[j] = ldg4(bq + 16 * j);
+                qkv_group(qa, xn, ws, ringl, active);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) qa[j] = qa[j] * a.qscale;
+            }
+#pragma unroll 1
+            for (int kv = 0; kv < 2; ++kv) {
+                f4 acc[7];
+                const float* bk = W.bqkv + (size_t)(h * 3 + 1 + kv) * 112 + 4 * g;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc[j] = ldg4(bk + 16 * j);
+                qkv_group(acc, xn, ws, ringl, active);
+                // every wave passed a stream barrier since its last read of the previous head's K/V (the out-projection
+                // and the Q group lie in between), so the rows can be overwritten
+                if (active) {
+                    float* row = (kv ? Vb : Kb) + (tokbase + 16 * tt + c) * kKV + 4 * g;
+#pragma unroll
+                    for (int j = 0; j < 7; ++j)
+                        if (j < 6 || g == 0) *reinterpret_cast<f4*>(row + 16 * j) = acc[j];     // cols >= 100 belong to the next row
+                }
+            }
+            STAMP(5 + 8 * l);
+            __syncthreads();
+            STAMP(6 + 8 * l);
+
+            // ================= attention of head h for this wave's 16 queries =================
+            f4 oa[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) oa[j] = zero4();
+            if (active) {
+                f4 sa[TPW];
+#pragma unroll
+                for (int kt = 0; kt < TPW; ++kt) sa[kt] = zero4();
+                // S^T[key][query] = sum_d K[key][d] * Q^T[d][query]; key tiles in chunks of 4
+#pragma unroll
+                for (int kh = 0; kh < TPW / 4; ++kh) {
+                    const float* kbase = Kb + (tokbase + 64 * kh + c) * kKV + 4 * g;
+                    f4 kf[2][4];
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) kf[0][kt] = lds4(kbase + 16 * kt * kKV);
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        if (j + 1 < 7) {
+#pragma unroll
+                            for (int kt = 0; kt < 4; ++kt) kf[(j + 1) & 1][kt] = lds4(kbase + 16 * kt * kKV + 16 * (j + 1));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma_group<4>(&sa[4 * kh], kf[j & 1], qa[j]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                // softmax over keys (rows 16kt + 4g + r); keys >= T do not exist
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = 16 * kt + 4 * g + r;
+                        if (key >= T) sa[kt][r] = -INFINITY;
+                        mx = fmaxf(mx, sa[kt][r]);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sa[kt][r] = expf(sa[kt][r] - mx); sum += sa[kt][r]; }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int kt = 0; kt < TPW; ++kt) sa[kt] *= inv;
+                // O^T[d][query] = sum_key V[key][d] * P^T[key][query]  (rows >= 100 are junk x zero weight columns)
+                {
+                    auto load_v = [&](f4 (&va)[7], int kt) {
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) {
+                            const float* vp = Vb + (tokbase + 16 * kt + 4 * g) * kKV + 16 * j + c;
+                            va[j].x = vp[0]; va[j].y = vp[kKV]; va[j].z = vp[2 * kKV]; va[j].w = vp[3 * kKV];
+                        }
+                    };
+                    f4 va[2][7];
+                    load_v(va[0], 0);
+#pragma unroll
+                    for (int kt = 0; kt < TPW; ++kt) {
+                        if (kt + 1 < TPW) load_v(va[(kt + 1) & 1], kt + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma_group<7>(oa, va[kt & 1], sa[kt]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            STAMP(7 + 8 * l);
+            // ================= out-projection, accumulated straight into the residual: x^T += Wo[:, head h] . O^T =================
+            // 7 steps (d-chunk j) of 13 fragments (n-tile i), sub-groups (4,3,3,3) read one ahead
+            ws.fit(13);
+            {
+                f4 fs[2][4];
+                if (active) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) fs[0][v] = lds4(ringl + (ws.pos + v) * kFrag);
+                }
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const int pcur = ws.pos;
+                    const int pnext = ws.next_pos(13, 13);
+                    if (active) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int gi = 4 * j + q;
+                            const int i0 = q == 0 ? 0 : 4 + 3 * (q - 1), n = q == 0 ? 4 : 3;
+                            if (q + 1 < 4) {
+                                const int j0 = 4 + 3 * q;
+#pragma unroll
+                                for (int v = 0; v < 3; ++v) fs[(gi + 1) & 1][v] = lds4(ringl + (pcur + j0 + v) * kFrag);
+                            } else if (j + 1 < 7) {
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) fs[(gi + 1) & 1][v] = lds4(ringl + (pnext + v) * kFrag);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (n == 4) mma_group<4>(&x[i0], fs[gi & 1], oa[j]); else mma_group<3>(&x[i0], fs[gi & 1], oa[j]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    ws.advance(13);
+                    if (j + 1 < 7) ws.fit(13);
+                }
+            }
+        }
+        // out-projection bias
+#pragma unroll
+        for (int i = 0; i < kNT; ++i) x[i] = x[i] + ldg4(W.bo + 16 * i + 4 * g);
+
+        STAMP(8 + 8 * l);
+        // ================= LN1 + FFN: 25 steps of two hidden tiles; W1 fragments [k-chunk][tile], W2 [tile][n-tile] =================
+        if (active) layernorm(xn, x, misc + kMiscLn + 2 * kDP, misc + kMiscLn + 3 * kDP, g);
+        STAMP(9 + 8 * l);
+        f4 y[kNT];
+#pragma unroll
+        for (int i = 0; i < kNT; ++i) y[i] = zero4();
+        ws.align26();
+#pragma unroll 1
+        for (int p = 0; p < 25; ++p) {
+            f4 h[2];
+            if (active) {
+                const float* abuf = ringl + ws.pos * kFrag;
+                h[0] = lds4(misc + kMiscB1 + 32 * p + 4 * g);
+                h[1] = lds4(misc + kMiscB1 + 32 * p + 16 + 4 * g);
+                f4 sa[2][2];
+                sa[0][0] = lds4(abuf); sa[0][1] = lds4(abuf + kFrag);
+#pragma unroll
+                for (int kc = 0; kc < kKC; ++kc) {
+                    const int cur = kc & 1;
+                    if (kc + 1 < kKC) {
+                        sa[cur ^ 1][0] = lds4(abuf + (size_t)(2 * (kc + 1)) * kFrag);
+                        sa[cur ^ 1][1] = lds4(abuf + (size_t)(2 * (kc + 1) + 1) * kFrag);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_group<2>(h, sa[cur], xn[kc]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    h[u].x = gelu_erf(h[u].x); h[u].y = gelu_erf(h[u].y); h[u].z = gelu_erf(h[u].z); h[u].w = gelu_erf(h[u].w);   // DyGFormer.py:458
+                }
+            }
+            ws.advance(26);
+            if (active) {
+                const float* bbuf = ringl + ws.pos * kFrag;
+                f4 fs[2][4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) fs[0][v] = lds4(bbuf + (size_t)v * kFrag);
+#pragma unroll
+                for (int gi = 0; gi < 8; ++gi) {
+                    const int u = gi >> 2, q = gi & 3;
+                    const int i0 = q == 0 ? 0 : 4 + 3 * (q - 1), n = q == 0 ? 4 : 3;
+                    if (gi + 1 < 8) {
+                        const int u2 = (gi + 1) >> 2, q2 = (gi + 1) & 3;
+                        const int j0 = q2 == 0 ? 0 : 4 + 3 * (q2 - 1), n2 = q2 == 0 ? 4 : 3;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) if (v < n2) fs[(gi + 1) & 1][v] = lds4(bbuf + (size_t)(u2 * 13 + j0 + v) * kFrag);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (n == 4) mma_group<4>(&y[i0], fs[gi & 1], h[u]); else mma_group<3>(&y[i0], fs[gi & 1], h[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            ws.advance(26);
+        }
+#pragma unroll
+        for (int i = 0; i < kNT; ++i) x[i] = x[i] + (y[i] + ldg4(W.b2 + 16 * i + 4 * g));
+        STAMP(10 + 8 * l);
+        tap_store<TPW>(x, a.tap_layer[l], b, a.Tmax, T, tt, c, g);
+    }
+
+    STAMP(3 + 8 * a.NL);
+    // ================= per-side mean over tokens + output layer (DyGFormer.py:181-192) =================
+    __syncthreads();        // K/V are dead: reuse as scratch
+    {
+        float* pool = Kb;                        // [wave][side][208]
+        const int tok = 16 * tt + c;
+        const bool in_src = tok < Ts, in_dst = tok >= Ts && tok < T;
+#pragma unroll
+        for (int i = 0; i < kNT; ++i) {
+            f4 vs = in_src ? x[i] : zero4();
+            f4 vd = in_dst ? x[i] : zero4();
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vs[r] += __shfl_xor(vs[r], o, 64);
+                    vd[r] += __shfl_xor(vd[r], o, 64);
+                }
+            }
+            if (c == 0) {
+                *reinterpret_cast<f4*>(pool + (wave * 2 + 0) * kDP + 16 * i + 4 * g) = vs;
+                *reinterpret_cast<f4*>(pool + (wave * 2 + 1) * kDP + 16 * i + 4 * g) = vd;
+            }
+        }
+        __syncthreads();
+        float* mean = Vb;                        // [pair][side][208]
+        const int Td = T - Ts;
+        for (int i = ptid; i < 2 * kDP; i += PT) {
+            const int side = i / kDP, n = i % kDP;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < TPW; ++w) s += pool[((pi * TPW + w) * 2 + side) * kDP + n];
+            mean[pi * 2 * kDP + i] = s / (float)(side ? Td : Ts);
+        }
+        __syncthreads();
+        // output layer: wave tt of the pair sums k in [KW*tt, KW*tt + KW) for every output column
+        constexpr int KW = kD / TPW;             // 50 or 25
+        float* part = Vb + NP * 2 * kDP;         // [wave][side][Fn]
+        const float* mp = mean + pi * 2 * kDP;
+        for (int j = lane; j < a.Fn; j += 64) {
+            float ps = 0.f, pd = 0.f;
+#pragma unroll 5
+            for (int k = KW * tt; k < KW * tt + KW; ++k) {
+                const float wv = a.outT[(size_t)k * a.Fn + j];
+                ps = fmaf(mp[k], wv, ps);
+                pd = fmaf(mp[kDP + k], wv, pd);
+            }
+            part[(wave * 2 + 0) * a.Fn + j] = ps;
+            part[(wave * 2 + 1) * a.Fn + j] = pd;
+        }
+        __syncthreads();
+        if (pair_ok) {
+            for (int i = ptid; i < 2 * a.Fn; i += PT) {
+                const int side = i / a.Fn, j = i % a.Fn;
+                float acc = a.outb[j];
+#pragma unroll
+                for (int w = 0; w < TPW; ++w) acc += part[((pi * TPW + w) * 2 + side) * a.Fn + j];
+                (side ? a.out_dst : a.out_src)[b * a.Fn + j] = acc;
+            }
+        }
+    }
+    STAMP(4 + 8 * a.NL);
+}
+
+// ================================================================================================
+// packing: the stream is described on the host as a list of fragment descriptors in consumption order (with the pad
+// fragments the ring rule asks for), uploaded, and materialised by one kernel.
+// ================================================================================================
+struct FragDesc {
+    const float* src;     // nullptr = pad fragment (zeros)
+    int ld;
+    int r0, rmax;         // element (c,g,t): row = r0 + c, valid iff 0 <= row < rmax
+    int c0, cmax;         //                  col = c0 + 4g + t, valid iff col < cmax
+};
+
+__global__ void k_pack_stream(const FragDesc* __restrict__ desc, int64_t nfrag, float* __restrict__ dst) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nfrag * kFrag) return;
+    const int t = idx & 3, lane = (idx >> 2) & 63;
+    const FragDesc d = desc[idx >> 8];
+    const int c = lane & 15, g = lane >> 4;
+    const int row = d.r0 + c, col = d.c0 + 4 * g + t;
+    float v = 0.f;
+    if (d.src != nullptr && row >= 0 && row < d.rmax && col < d.cmax) v = d.src[(size_t)row * d.ld + col];
+    dst[idx] = v;
+}
+
+__global__ void k_pack_vec3(const float* __restrict__ src, int n_valid, int src_off, float* __restrict__ dst, int dst_off, int n_total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    dst[dst_off + i] = i < n_valid ? src[src_off + i] : 0.f;
+}
+
+// host mirror of WStream's position rule
+struct StreamBuilder {
+    std::vector<FragDesc> frags;
+    int pos = 0;
+    void pad(int n) { for (int i = 0; i < n; ++i) frags.push_back(FragDesc{nullptr, 0, 0, 0, 0, 0}); pos = (pos + n) % kRing; }
+    void fit(int n) { if (pos + n > kRing) pad(kRing - pos); }
+    void align26() { if (pos != 0 && pos != 26) pad(pos < 26 ? 26 - pos : kRing - pos); }
+    void put(const float* src, int ld, int r0, int rmax, int c0, int cmax) { frags.push_back(FragDesc{src, ld, r0, rmax, c0, cmax}); pos = (pos + 1) % kRing; }
+};
+
+static void build_stream(const Dims& d, const dygnn_dygformer_weights* w, StreamBuilder& sb, int (&nchunk)[4]) {
+    const float* pw[4] = {w->proj_node_w, w->proj_edge_w, w->proj_time_w, w->proj_cooc_w};
+    const int K[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * d.C};
+    sb.fit(4);
+    for (int ch = 0; ch < 4; ++ch) {
+        nchunk[ch] = (K[ch] + 15) / 16;
+        const int t0 = (kC * ch) / 16;
+        for (int kc = 0; kc < nchunk[ch]; ++kc)
+            for (int u = 0; u < 4; ++u) sb.put(pw[ch], K[ch], 16 * (t0 + u) - kC * ch, kC, 16 * kc, K[ch]);
+    }
+    for (int l = 0; l < d.NL; ++l) {
+        const dygnn_encoder_layer_weights& L = w->layers[l];
+        for (int h = 0; h < 2; ++h) {
+            for (int part = 0; part < 3; ++part) {           // q, k, v row blocks of in_proj
+                sb.fit(7);
+                for (int kc = 0; kc < kKC; ++kc) {
+                    for (int j = 0; j < 7; ++j)
+                        sb.put(L.in_proj_weight + (size_t)part * kD * kD, kD, kHD * h + 16 * j, kHD * (h + 1), 16 * kc, kD);
+                    if (kc + 1 < kKC) sb.fit(7);
+                }
+            }
+            sb.fit(13);
+            for (int j = 0; j < 7; ++j) {                    // out-projection: [d-chunk j][n-tile i], columns of head h
+                for (int i = 0; i < kNT; ++i) sb.put(L.out_proj_weight, kD, 16 * i, kD, kHD * h + 16 * j, kHD * (h + 1));
+                if (j + 1 < 7) sb.fit(13);
+            }
+        }
+        sb.align26();
+        for (int p = 0; p < 25; ++p) {
+            for (int kc = 0; kc < kKC; ++kc)
+                for (int u = 0; u < 2; ++u) sb.put(L.ffn0_weight, kD, 16 * (2 * p + u), kHid, 16 * kc, kD);
+            for (int u = 0; u < 2; ++u)
+                for (int i = 0; i < kNT; ++i) sb.put(L.ffn1_weight, kHid, 16 * i, kD, 16 * (2 * p + u), kHid);
+        }
+    }
+}
+
+struct PackLayout3 {       // float offsets relative to PackedLayout.fused3
+    size_t bias_x;
+    struct L { size_t ln, bqkv, bo, b1, b2; } layer[DYGNN_MAX_LAYERS];
+    size_t stream; int64_t nfrag; int nstages;
+    size_t desc;           // FragDesc table (device copy), 8-byte aligned
+    size_t total;
+};
+
+static int64_t stream_frags(const Dims& d) {
+    // fragment count of build_stream without touching weights: run the builder with null sources
+    dygnn_dygformer_weights w{};
+    static float dummy;
+    w.proj_node_w = w.proj_edge_w = w.proj_time_w = w.proj_cooc_w = &dummy;
+    dygnn_encoder_layer_weights lw{};
+    lw.in_proj_weight = lw.out_proj_weight = lw.ffn0_weight = lw.ffn1_weight = &dummy;
+    for (int l = 0; l < d.NL; ++l) w.layers[l] = lw;
+    StreamBuilder sb;
+    int nchunk[4];
+    build_stream(d, &w, sb, nchunk);
+    return (int64_t)sb.frags.size();
+}
+
+static PackLayout3 make_layout3(const Dims& d) {
+    PackLayout3 f;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~size_t(63); return r; };
+    f.bias_x = take(kDP);
+    for (int l = 0; l < d.NL; ++l) {
+        auto& L = f.layer[l];
+        L.ln = take(4 * kDP); L.bqkv = take(2 * 3 * 112); L.bo = take(kDP); L.b1 = take(kHid); L.b2 = take(kDP);
+    }
+    f.nfrag = stream_frags(d);
+    f.nstages = (int)((f.nfrag + kStage - 1) / kStage);
+    f.stream = take((size_t)(f.nstages + 1) * kStage * kFrag);
+    f.desc = take(((size_t)f.nfrag * sizeof(FragDesc) + 3) / 4);
+    f.total = o;
+    return f;
+}
+
+bool supported(const Dims& d) {
+    if (!(d.C == kC && d.H == 2 && d.Fn % 4 == 0 && d.Fe % 4 == 0 && d.Ft % 4 == 0 && d.Fn >= 16 && d.Fe >= 16 && d.Ft >= 16 &&
+          d.Fn <= 512 && d.NL <= DYGNN_MAX_LAYERS && d.Tmax <= 128)) return false;
+    const int np = d.Tmax <= 64 ? 2 : 1;
+    // window arrays: 5 x (2 sides, each padded to a multiple of 4) ints per pair in the K/V region; k/50 multiply-shift range
+    return (size_t)np * 5 * (2 * (size_t)((d.Smax + 3) & ~3)) <= (size_t)kScratchFloats && d.P * kC < 12000;
+}
+
+size_t packed_floats(const Dims& d) { return supported(d) ? make_layout3(d).total : 0; }
+
+static int pack_vec(const float* src, int n_valid, int src_off, float* dst, int dst_off, int n_total, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_vec3, dim3((n_total + 255) / 256), dim3(256), 0, s, src, n_valid, src_off, dst, dst_off, n_total);
+    DYGNN_LAUNCH_CHECK();
+    return DYGNN_OK;
+}
+
+int pack(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, float* packed, hipStream_t s) {
+    const PackLayout3 f = make_layout3(d);
+    float* base = packed + pl.fused3;
+    DYGNN_HIP(hipMemsetAsync(base, 0, f.total * sizeof(float), s));
+    const float* pb[4] = {w->proj_node_b, w->proj_edge_b, w->proj_time_b, w->proj_cooc_b};
+    for (int ch = 0; ch < 4; ++ch)
+        if (int rc = pack_vec(pb[ch], kC, 0, base + f.bias_x, kC * ch, kC, s)) return rc;
+    for (int l = 0; l < d.NL; ++l) {
+        const dygnn_encoder_layer_weights& L = w->layers[l];
+        const auto& F = f.layer[l];
+        const float* ln[4] = {L.norm0_weight, L.norm0_bias, L.norm1_weight, L.norm1_bias};
+        for (int i = 0; i < 4; ++i)
+            if (int rc = pack_vec(ln[i], kD, 0, base + F.ln, i * kDP, kDP, s)) return rc;
+        for (int h = 0; h < 2; ++h)
+            for (int part = 0; part < 3; ++part)       // head rows 100h .. 100h+99 of the q/k/v bias, zero padded to 112
+                if (int rc = pack_vec(L.in_proj_bias, kHD, part * kD + kHD * h, base + F.bqkv, (h * 3 + part) * 112, 112, s)) return rc;
+        if (int rc = pack_vec(L.out_proj_bias, kD, 0, base + F.bo, 0, kDP, s)) return rc;
+        if (int rc = pack_vec(L.ffn0_bias, kHid, 0, base + F.b1, 0, kHid, s)) return rc;
+        if (int rc = pack_vec(L.ffn1_bias, kD, 0, base + F.b2, 0, kDP, s)) return rc;
+    }
+    StreamBuilder sb;
+    int nchunk[4];
+    build_stream(d, w, sb, nchunk);
+    if ((int64_t)sb.frags.size() != f.nfrag) { set_error("pack: stream builder mismatch"); return DYGNN_E_INVALID; }
+    FragDesc* ddesc = reinterpret_cast<FragDesc*>(base + f.desc);
+    DYGNN_HIP(hipMemcpyAsync(ddesc, sb.frags.data(), sb.frags.size() * sizeof(FragDesc), hipMemcpyHostToDevice, s));
+    const int64_t total = f.nfrag * kFrag;
+    hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, ddesc, f.nfrag, base + f.stream);
+    DYGNN_LAUNCH_CHECK();
+    DYGNN_HIP(hipStreamSynchronize(s));     // the descriptor table is copied from this call's host vector
+    return DYGNN_OK;
+}
+
+}  // namespace v3
+
+int window_lengths_device(const Dims& d, const dygnn_csr* csr, const int64_t* src, const int64_t* dst, const double* times,
+                          int64_t B, int64_t G, char* ws, const WorkspaceLayout& wl, hipStream_t s);   // dygformer_generic.hip
+
+bool fused3_supported(const Dims& d) { return v3::supported(d); }
+size_t fused3_packed_floats(const Dims& d) { return v3::packed_floats(d); }
+int pack_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, float* packed, hipStream_t s) {
+    return v3::pack(d, pl, w, packed, s);
+}
+
+int forward_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, const float* packed,
+                   const dygnn_csr* csr, const float* node_feat, const float* edge_feat, const int64_t* src,
+                   const int64_t* dst, const double* times, int64_t B, int64_t G, float* out_src, float* out_dst, char* ws,
+                   const WorkspaceLayout& wl, const dygnn_dygformer_taps* taps, hipStream_t s) {
+    using namespace v3;
+    if (!supported(d)) { set_error("fused kernel: unsupported shape"); return DYGNN_E_UNSUPPORTED; }
+    if (int rc = window_lengths_device(d, csr, src, dst, times, B, G, ws, wl, s)) return rc;
+    const PackLayout3 f = make_layout3(d);
+    const float* base = packed + pl.fused3;
+    Args a{};
+    a.indptr = csr->indptr; a.nbr = csr->nbr; a.eid = csr->eid; a.ts = csr->ts;
+    a.src = src; a.dst = dst; a.times = times;
+    a.hist_len = reinterpret_cast<const int32_t*>(ws + wl.hist_len);
+    a.end_pos = reinterpret_cast<const int64_t*>(ws + wl.end_pos);
+    a.cd = reinterpret_cast<const CallDims*>(ws + wl.dims);
+    a.node_feat = node_feat; a.edge_feat = edge_feat; a.time_w = w->time_w; a.time_b = w->time_b; a.lut = packed + pl.lut;
+    a.stream = base + f.stream; a.nstages = f.nstages;
+    a.bias_x = base + f.bias_x;
+    for (int l = 0; l < d.NL; ++l) {
+        const auto& F = f.layer[l];
+        LayerP& L = a.layer[l];
+        L.ln = base + F.ln; L.bqkv = base + F.bqkv; L.bo = base + F.bo; L.b1 = base + F.b1; L.b2 = base + F.b2;
+        a.tap_layer[l] = taps ? taps->layer_out[l] : nullptr;
+    }
+    a.outT = packed + pl.outputT; a.outb = w->output_b;
+    a.out_src = out_src; a.out_dst = out_dst;
+    a.tap_enc = taps ? taps->encoder_input : nullptr;
+    a.stamps = taps ? reinterpret_cast<unsigned long long*>(taps->phase_cycles) : nullptr;
+    a.B = B; a.G = G; a.Fn = d.Fn; a.Fe = d.Fe; a.Ft = d.Ft; a.P = d.P; a.L = d.L; a.NL = d.NL; a.Tmax = d.Tmax;
+    const int K[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * d.C};
+    for (int ch = 0; ch < 4; ++ch) a.nchunk[ch] = (K[ch] + 15) / 16;
+    a.qscale = (float)sqrt(1.0 / (double)d.hd);
+    if (taps && taps->seq_lens) DYGNN_HIP(hipMemcpyAsync(taps->seq_lens, ws + wl.dims + 2 * sizeof(int32_t), 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    static bool attr_set = false;
+    if (!attr_set) {
+        DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        attr_set = true;
+    }
+    if (d.Tmax <= 64) hipLaunchKernelGGL(k_dygformer_fused3<4>, dim3((unsigned)((B + 1) / 2)), dim3(512), kLdsBytes, s, a);
+    else hipLaunchKernelGGL(k_dygformer_fused3<8>, dim3((unsigned)B), dim3(512), kLdsBytes, s, a);
+    DYGNN_LAUNCH_CHECK();
+    return DYGNN_OK;
+}
+
+}  // namespace dygnn

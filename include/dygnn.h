@@ -158,8 +158,10 @@ size_t dygnn_dygformer_workspace_bytes(const dygnn_dygformer_config* cfg_host, i
  * the result of every group is bit-identical to a separate reference call on that group, so several
  * reference calls (e.g. the positive and the negative call of a step, evaluate_models_utils.py:126-136, or
  * several evaluation batches) run as ONE grid that keeps all 256 CUs busy.  G = 0 or G >= batch: one group.
- * impl: 0 = auto (fused MFMA kernel when the shape is supported, else generic),
- *       1 = generic multi-kernel path (any shape), 2 = fused kernel (error if unsupported). */
+ * impl: 0 = auto (a fused MFMA kernel when the shape is supported, else generic),
+ *       1 = generic multi-kernel path (any shape),
+ *       2 = fused kernel, wave-pair layout (<= 64 tokens per pair; error if unsupported),
+ *       3 = fused kernel, token-owner layout (<= 128 tokens per pair; error if unsupported). */
 int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg_host, const dygnn_dygformer_weights* w_host,
                             const void* packed, const dygnn_csr* csr_host,
                             const float* node_feat, const float* edge_feat,

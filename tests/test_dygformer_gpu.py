@@ -14,8 +14,8 @@ from tests import golden_cases as gc
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
-IMPLS = {"generic": 1, "fused": 2, "auto": 0}
-FUSED_UNSUPPORTED = {"bip_p8_l512"}      # 128 tokens per pair: generic path only (for now)
+IMPLS = {"generic": 1, "fused": 2, "fused3": 3, "auto": 0}
+FUSED_UNSUPPORTED = {"bip_p8_l512"}      # 128 tokens per pair: the wave-pair fused kernel (impl 2) stops at 64
 
 
 def close(got, want, what=""):
@@ -141,7 +141,7 @@ def test_wikipedia_scale_batch_against_oracle():
     src, dst, t = data.src_node_ids[idx], data.dst_node_ids[idx], data.node_interact_times[idx]
     with torch.no_grad():
         os_, od = orc.dygformer_forward(params, nf, ef, adj, src, dst, t, 2, 64)
-        for impl in (1, 2):
+        for impl in (1, 2, 3):
             model.impl = impl
             gs, gd = model.compute_src_dst_node_temporal_embeddings(src, dst, t)
             close(gs.cpu().numpy(), os_.numpy(), f"impl {impl} src")
@@ -161,7 +161,7 @@ def test_many_calls_in_one_launch_match_separate_calls():
     src = np.stack([d.src_node_ids[r] for r in rows])
     dst = np.stack([d.dst_node_ids[r] for r in rows])
     t = np.stack([d.node_interact_times[r] for r in rows])
-    for impl in (1, 2):
+    for impl in (1, 2, 3):
         model.impl = impl
         with torch.no_grad():
             many_s, many_d = model.compute_src_dst_node_temporal_embeddings_many(src, dst, t)
