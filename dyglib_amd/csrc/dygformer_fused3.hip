@@ -37,9 +37,9 @@ constexpr int kLdsK = 0;
 constexpr int kLdsV = kTokWG * kKV;                 // 12800
 constexpr int kLdsRing = 2 * kTokWG * kKV + 16;     // 16 floats of slack: tile 6 of the last row reads 12 floats past it
 constexpr int kLdsMisc = kLdsRing + kRing * kFrag;  // 38928 floats = 155,712 B
-constexpr int kMiscLn = 0;            // [4][208]: ln0 gamma, ln0 beta, ln1 gamma, ln1 beta
-constexpr int kMiscB1 = 4 * kDP;      // [800]
-constexpr int kMiscFloats = 4 * kDP + kHid;         // 1632
+constexpr int kMiscB1 = 0;            // [2][800]: FFN hidden bias, double-buffered by layer parity (no barrier needed:
+                                      // dozens of stream barriers lie between a buffer's write and its reads / reuse)
+constexpr int kMiscFloats = 2 * kHid;               // 1600
 constexpr int kLdsBytes = 160 * 1024;
 static_assert((kLdsMisc + kMiscFloats) * 4 <= kLdsBytes, "LDS budget");
 constexpr int kScratchFloats = 2 * kTokWG * kKV;    // prologue window arrays live in the K/V region
@@ -98,9 +98,7 @@ __device__ __forceinline__ float erf_as(float x) {
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f)); }
 
 struct LayerP {
-    const float* ln;      // [4][208]
-    const float* bqkv;    // [2 heads][q,k,v][7 tiles][16], rows >= 100 of a head are zero
-    const float *bo, *b1, *b2;   // [208], [800], [208]
+    const float* b1;      // [800]; every other per-layer vector travels in the weight stream
 };
 
 struct Args {
@@ -110,6 +108,7 @@ struct Args {
     const float *node_feat, *edge_feat, *time_w, *time_b, *lut;
     const float* stream; int nstages;
     const float* bias_x;          // [208] projection biases in model-dim order
+    const float* outfrag;         // output layer as fragments [ceil(Fn/16) tiles][13 k-chunks]
     LayerP layer[DYGNN_MAX_LAYERS];
     const float *outT, *outb;     // output layer: transposed [200][Fn], bias [Fn]
     float *out_src, *out_dst;
@@ -168,15 +167,25 @@ struct WStream {
     }
 };
 
+// Diagnostic build (-DDYGNN_STAMPS): every wave accumulates s_memtime ticks per phase category and the last four
+// workgroups of the grid store them: taps.phase_cycles[wg][wave][cat]; cat 31 = total.
 #ifdef DYGNN_STAMPS
-#define STAMP(i)                                                                                   \
+#define TDECL unsigned long long tacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tk_ = __builtin_amdgcn_s_memtime(); const unsigned long long tk0_ = tk_
+#define TACC(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc_[i] += t_ - tk_; tk_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TSTORE()                                                                                   \
     do {                                                                                           \
-        if (a.stamps != nullptr && lane == 0 && blockIdx.x + 4 >= gridDim.x)                       \
-            a.stamps[((size_t)(blockIdx.x + 4 - gridDim.x) * 8 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime();   \
+        if (a.stamps != nullptr && lane == 0 && blockIdx.x + 4 >= gridDim.x) {                     \
+            unsigned long long* o_ = a.stamps + ((size_t)(blockIdx.x + 4 - gridDim.x) * 8 + wave) * 32;   \
+            for (int i_ = 0; i_ < 12; ++i_) o_[i_] = tacc_[i_];                                    \
+            o_[31] = tk_ - tk0_;                                                                   \
+        }                                                                                          \
     } while (0)
 #else
-#define STAMP(i) do { } while (0)
+#define TDECL do { } while (0)
+#define TACC(i) do { } while (0)
+#define TSTORE() do { } while (0)
 #endif
+enum { T_WIN = 0, T_PROJ, T_LN, T_QKV, T_QKVBAR, T_ATTN, T_OPROJ, T_FFN, T_POOL, T_MISC, T_POOL1, T_POOL2 };
 
 // LayerNorm of the register-resident X^T (two-pass, biased variance, eps 1e-5); gamma/beta from LDS
 __device__ __forceinline__ void layernorm(f4 (&xn)[kNT], const f4 (&x)[kNT], const float* gamma, const float* beta, int g) {
@@ -207,25 +216,30 @@ __device__ __forceinline__ void layernorm(f4 (&xn)[kNT], const f4 (&x)[kNT], con
     }
 }
 
-// acc[7] += W(7 tiles of one head's q, k or v) . xn : 13 stream steps of 7 fragments [k-chunk][tile]
+// acc[7] += W(7 tiles of one head's q, k or v) . xn : 13 stream steps of 7 fragments [k-chunk][tile], each multiplied
+// as sub-groups of 4 and 3 tiles whose fragments are read one sub-group ahead (8 fragments live instead of 14)
 __device__ __forceinline__ void qkv_group(f4 (&acc)[7], const f4 (&xn)[kNT], WStream& ws, const float* ringl, bool active) {
-    f4 fa[2][7];
+    f4 fs[2][4];
     ws.fit(7);
     if (active) {
 #pragma unroll
-        for (int u = 0; u < 7; ++u) fa[0][u] = lds4(ringl + (ws.pos + u) * kFrag);
+        for (int u = 0; u < 4; ++u) fs[0][u] = lds4(ringl + (ws.pos + u) * kFrag);
     }
 #pragma unroll
     for (int kc = 0; kc < kKC; ++kc) {
-        const int cur = kc & 1;
         if (active) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) fs[1][u] = lds4(ringl + (ws.pos + 4 + u) * kFrag);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_group<4>(&acc[0], fs[0], xn[kc]);
+            __builtin_amdgcn_sched_barrier(0);
             if (kc + 1 < kKC) {
                 const int p1 = ws.next_pos(7, 7);
 #pragma unroll
-                for (int u = 0; u < 7; ++u) fa[cur ^ 1][u] = lds4(ringl + (p1 + u) * kFrag);
+                for (int u = 0; u < 4; ++u) fs[0][u] = lds4(ringl + (p1 + u) * kFrag);
             }
             __builtin_amdgcn_sched_barrier(0);
-            mma_group<7>(acc, fa[cur], xn[kc]);
+            mma_group<3>(&acc[4], fs[1], xn[kc]);
             __builtin_amdgcn_sched_barrier(0);
         }
         ws.advance(7);
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
     const bool pair_ok = b < a.B;
     const int ptid = tid - pi * PT;
 
-    STAMP(0);
+    TDECL;
     CallDims cd{};
     if (pair_ok) cd = a.cd[b / a.G];
     const int Ss = cd.S_s, Sd = cd.S_d, Ts = cd.T_s, T = cd.T;
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
     }
     __syncthreads();
 
-    STAMP(1);
+    TACC(T_WIN);
     // ---- resident residual stream X^T: 13 tiles (rows 16i+4g+r) x token c of tile tt
     f4 x[kNT];
 #pragma unroll
@@ -405,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
         project(std::integral_constant<int, 6>{}, a.nchunk[2], a.Ft, timef);
         project(std::integral_constant<int, 9>{}, a.nchunk[3], 1 << 30, coocf);
     }
-    STAMP(2);
+    TACC(T_PROJ);
     __syncthreads();     // everyone is done with the window arrays
     for (int i = tid; i < kScratchFloats / 4; i += 512) reinterpret_cast<f4*>(lds)[i] = zero4();
     tap_store<TPW>(x, a.tap_enc, b, a.Tmax, T, tt, c, g);
@@ -416,24 +430,27 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
 
     for (int l = 0; l < a.NL; ++l) {
         const LayerP& W = a.layer[l];
-        STAMP(3 + 8 * l);
-        __syncthreads();                 // previous layer is done with ln / b1 (and the re-zeroing above is complete)
-        for (int i = tid; i < 4 * kDP; i += 512) misc[kMiscLn + i] = W.ln[i];
-        for (int i = tid; i < kHid; i += 512) misc[kMiscB1 + i] = W.b1[i];
-        __syncthreads();
+        TACC(T_MISC);
+        float* b1s = misc + kMiscB1 + (l & 1) * kHid;
+        for (int i = tid; i < kHid; i += 512) b1s[i] = W.b1[i];
+        if (l == 0) __syncthreads();     // the re-zeroing of K/V above is complete before the first K/V rows are written
 
         f4 xn[kNT];
-        if (active) layernorm(xn, x, misc + kMiscLn, misc + kMiscLn + kDP, g);
-        STAMP(4 + 8 * l);
+        ws.fit(2);                       // LN0 gamma, beta: two vector fragments
+        if (active) layernorm(xn, x, lds + kLdsRing + ws.pos * kFrag, lds + kLdsRing + (ws.pos + 1) * kFrag, g);
+        ws.advance(2);
+        TACC(T_LN);
 
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
             // ================= Q, K, V of head h =================
             f4 qa[7];
             {
-                const float* bq = W.bqkv + (size_t)(h * 3 + 0) * 112 + 4 * g;
+                ws.fit(1);               // bias fragment: rows 100h .. 100h+99 of the q bias, zero padded
+                const float* bq = lds + kLdsRing + ws.pos * kFrag + 4 * g;
 #pragma unroll
-                for (int j = 0; j < 7; ++j) qa[j] = ldg4(bq + 16 * j);
+                for (int j = 0; j < 7; ++j) qa[j] = lds4(bq + 16 * j);
+                ws.advance(1);
                 qkv_group(qa, xn, ws, ringl, active);
 #pragma unroll
                 for (int j = 0; j < 7; ++j) qa[j] = qa[j] * a.qscale;
@@ -441,9 +458,11 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
 #pragma unroll 1
             for (int kv = 0; kv < 2; ++kv) {
                 f4 acc[7];
-                const float* bk = W.bqkv + (size_t)(h * 3 + 1 + kv) * 112 + 4 * g;
+                ws.fit(1);
+                const float* bk = lds + kLdsRing + ws.pos * kFrag + 4 * g;
 #pragma unroll
-                for (int j = 0; j < 7; ++j) acc[j] = ldg4(bk + 16 * j);
+                for (int j = 0; j < 7; ++j) acc[j] = lds4(bk + 16 * j);
+                ws.advance(1);
                 qkv_group(acc, xn, ws, ringl, active);
                 // every wave passed a stream barrier since its last read of the previous head's K/V (the out-projection
                 // and the Q group lie in between), so the rows can be overwritten
@@ -454,9 +473,9 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                         if (j < 6 || g == 0) *reinterpret_cast<f4*>(row + 16 * j) = acc[j];     // cols >= 100 belong to the next row
                 }
             }
-            STAMP(5 + 8 * l);
+            TACC(T_QKV);
             __syncthreads();
-            STAMP(6 + 8 * l);
+            TACC(T_QKVBAR);
 
             // ================= attention of head h for this wave's 16 queries =================
             f4 oa[7];
@@ -526,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                     }
                 }
             }
-            STAMP(7 + 8 * l);
+            TACC(T_ATTN);
             // ================= out-projection, accumulated straight into the residual: x^T += Wo[:, head h] . O^T =================
             // 7 steps (d-chunk j) of 13 fragments (n-tile i), sub-groups (4,3,3,3) read one ahead
             ws.fit(13);
@@ -562,15 +581,23 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                     if (j + 1 < 7) ws.fit(13);
                 }
             }
+            TACC(T_OPROJ);
         }
-        // out-projection bias
+        // out-projection bias (one vector fragment)
+        ws.fit(1);
+        {
+            const float* bo = lds + kLdsRing + ws.pos * kFrag + 4 * g;
 #pragma unroll
-        for (int i = 0; i < kNT; ++i) x[i] = x[i] + ldg4(W.bo + 16 * i + 4 * g);
+            for (int i = 0; i < kNT; ++i) x[i] = x[i] + lds4(bo + 16 * i);
+        }
+        ws.advance(1);
 
-        STAMP(8 + 8 * l);
+        TACC(T_OPROJ);
         // ================= LN1 + FFN: 25 steps of two hidden tiles; W1 fragments [k-chunk][tile], W2 [tile][n-tile] =================
-        if (active) layernorm(xn, x, misc + kMiscLn + 2 * kDP, misc + kMiscLn + 3 * kDP, g);
-        STAMP(9 + 8 * l);
+        ws.fit(2);
+        if (active) layernorm(xn, x, lds + kLdsRing + ws.pos * kFrag, lds + kLdsRing + (ws.pos + 1) * kFrag, g);
+        ws.advance(2);
+        TACC(T_LN);
         f4 y[kNT];
 #pragma unroll
         for (int i = 0; i < kNT; ++i) y[i] = zero4();
@@ -580,8 +607,8 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
             f4 h[2];
             if (active) {
                 const float* abuf = ringl + ws.pos * kFrag;
-                h[0] = lds4(misc + kMiscB1 + 32 * p + 4 * g);
-                h[1] = lds4(misc + kMiscB1 + 32 * p + 16 + 4 * g);
+                h[0] = lds4(b1s + 32 * p + 4 * g);
+                h[1] = lds4(b1s + 32 * p + 16 + 4 * g);
                 f4 sa[2][2];
                 sa[0][0] = lds4(abuf); sa[0][1] = lds4(abuf + kFrag);
 #pragma unroll
@@ -623,13 +650,18 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
             }
             ws.advance(26);
         }
+        ws.fit(1);
+        {
+            const float* b2 = lds + kLdsRing + ws.pos * kFrag + 4 * g;
 #pragma unroll
-        for (int i = 0; i < kNT; ++i) x[i] = x[i] + (y[i] + ldg4(W.b2 + 16 * i + 4 * g));
-        STAMP(10 + 8 * l);
+            for (int i = 0; i < kNT; ++i) x[i] = x[i] + (y[i] + lds4(b2 + 16 * i));
+        }
+        ws.advance(1);
+        TACC(T_FFN);
         tap_store<TPW>(x, a.tap_layer[l], b, a.Tmax, T, tt, c, g);
     }
 
-    STAMP(3 + 8 * a.NL);
+    TACC(T_MISC);
     // ================= per-side mean over tokens + output layer (DyGFormer.py:181-192) =================
     __syncthreads();        // K/V are dead: reuse as scratch
     {
@@ -653,44 +685,42 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                 *reinterpret_cast<f4*>(pool + (wave * 2 + 1) * kDP + 16 * i + 4 * g) = vd;
             }
         }
+        TACC(T_POOL1);
         __syncthreads();
-        float* mean = Vb;                        // [pair][side][208]
+        TACC(T_POOL2);
+        // mean[col][208], col = 2*pair + side (4 columns of the 16-wide B operand are used; the rest multiply zeros)
+        float* mean = Vb;
         const int Td = T - Ts;
         for (int i = ptid; i < 2 * kDP; i += PT) {
             const int side = i / kDP, n = i % kDP;
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < TPW; ++w) s += pool[((pi * TPW + w) * 2 + side) * kDP + n];
-            mean[pi * 2 * kDP + i] = s / (float)(side ? Td : Ts);
+            mean[pi * 2 * kDP + i] = n < kD ? s / (float)(side ? Td : Ts) : 0.f;
         }
         __syncthreads();
-        // output layer: wave tt of the pair sums k in [KW*tt, KW*tt + KW) for every output column
-        constexpr int KW = kD / TPW;             // 50 or 25
-        float* part = Vb + NP * 2 * kDP;         // [wave][side][Fn]
-        const float* mp = mean + pi * 2 * kDP;
-        for (int j = lane; j < a.Fn; j += 64) {
-            float ps = 0.f, pd = 0.f;
-#pragma unroll 5
-            for (int k = KW * tt; k < KW * tt + KW; ++k) {
-                const float wv = a.outT[(size_t)k * a.Fn + j];
-                ps = fmaf(mp[k], wv, ps);
-                pd = fmaf(mp[kDP + k], wv, pd);
-            }
-            part[(wave * 2 + 0) * a.Fn + j] = ps;
-            part[(wave * 2 + 1) * a.Fn + j] = pd;
-        }
-        __syncthreads();
-        if (pair_ok) {
-            for (int i = ptid; i < 2 * a.Fn; i += PT) {
-                const int side = i / a.Fn, j = i % a.Fn;
-                float acc = a.outb[j];
+        // output layer on the matrix cores: out^T[j][col] = sum_k W[j][k] mean[col][k] + b[j]; wave w owns output tiles w, w+8, ...
+        // (each fragment is used by one wave only, so they come straight from global memory, all 13 of a tile in flight)
+        const int ntile = (a.Fn + 15) >> 4;
+        for (int jt = wave; jt < ntile; jt += 8) {
+            f4 fa[kKC];
 #pragma unroll
-                for (int w = 0; w < TPW; ++w) acc += part[((pi * TPW + w) * 2 + side) * a.Fn + j];
-                (side ? a.out_dst : a.out_src)[b * a.Fn + j] = acc;
+            for (int kc = 0; kc < kKC; ++kc) fa[kc] = ldg4(a.outfrag + ((size_t)jt * kKC + kc) * kFrag + lane * 4);
+            const int j0 = 16 * jt + 4 * g;
+            f4 acc0 = j0 < a.Fn ? ldg4(a.outb + j0) : zero4(), acc1 = zero4();
+#pragma unroll
+            for (int kc = 0; kc < kKC; ++kc) {
+                const f4 bm = c < 2 * NP ? lds4(mean + c * kDP + 16 * kc + 4 * g) : zero4();
+                if (kc & 1) { acc1 = mfma(fa[kc].x, bm.x, acc1); acc1 = mfma(fa[kc].y, bm.y, acc1); acc1 = mfma(fa[kc].z, bm.z, acc1); acc1 = mfma(fa[kc].w, bm.w, acc1); }
+                else { acc0 = mfma(fa[kc].x, bm.x, acc0); acc0 = mfma(fa[kc].y, bm.y, acc0); acc0 = mfma(fa[kc].z, bm.z, acc0); acc0 = mfma(fa[kc].w, bm.w, acc0); }
             }
+            const int64_t bo_ = (int64_t)blockIdx.x * NP + (c >> 1);
+            if (c < 2 * NP && bo_ < a.B && j0 < a.Fn)
+                *reinterpret_cast<f4*>(((c & 1) ? a.out_dst : a.out_src) + bo_ * a.Fn + j0) = acc0 + acc1;
         }
     }
-    STAMP(4 + 8 * a.NL);
+    TACC(T_POOL);
+    TSTORE();
 }
 
 // ================================================================================================
@@ -699,7 +729,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
 // ================================================================================================
 struct FragDesc {
     const float* src;     // nullptr = pad fragment (zeros)
-    int ld;
+    int ld;               // matrix fragment: row stride; -1: vector fragment, element e = src[c0 + e] for e < rmax
     int r0, rmax;         // element (c,g,t): row = r0 + c, valid iff 0 <= row < rmax
     int c0, cmax;         //                  col = c0 + 4g + t, valid iff col < cmax
 };
@@ -712,7 +742,10 @@ __global__ void k_pack_stream(const FragDesc* __restrict__ desc, int64_t nfrag, 
     const int c = lane & 15, g = lane >> 4;
     const int row = d.r0 + c, col = d.c0 + 4 * g + t;
     float v = 0.f;
-    if (d.src != nullptr && row >= 0 && row < d.rmax && col < d.cmax) v = d.src[(size_t)row * d.ld + col];
+    if (d.src != nullptr) {
+        if (d.ld < 0) { const int e = (int)(idx & 255); if (e < d.rmax) v = d.src[d.c0 + e]; }
+        else if (row >= 0 && row < d.rmax && col < d.cmax) v = d.src[(size_t)row * d.ld + col];
+    }
     dst[idx] = v;
 }
 
@@ -730,6 +763,7 @@ struct StreamBuilder {
     void fit(int n) { if (pos + n > kRing) pad(kRing - pos); }
     void align26() { if (pos != 0 && pos != 26) pad(pos < 26 ? 26 - pos : kRing - pos); }
     void put(const float* src, int ld, int r0, int rmax, int c0, int cmax) { frags.push_back(FragDesc{src, ld, r0, rmax, c0, cmax}); pos = (pos + 1) % kRing; }
+    void put_vec(const float* src, int off, int n) { put(src, -1, 0, n, off, 0); }     // floats [0, n) of the fragment = src[off ..]
 };
 
 static void build_stream(const Dims& d, const dygnn_dygformer_weights* w, StreamBuilder& sb, int (&nchunk)[4]) {
@@ -744,8 +778,13 @@ static void build_stream(const Dims& d, const dygnn_dygformer_weights* w, Stream
     }
     for (int l = 0; l < d.NL; ++l) {
         const dygnn_encoder_layer_weights& L = w->layers[l];
+        sb.fit(2);
+        sb.put_vec(L.norm0_weight, 0, kD);
+        sb.put_vec(L.norm0_bias, 0, kD);
         for (int h = 0; h < 2; ++h) {
             for (int part = 0; part < 3; ++part) {           // q, k, v row blocks of in_proj
+                sb.fit(1);
+                sb.put_vec(L.in_proj_bias, part * kD + kHD * h, kHD);      // head rows of the bias, zero beyond 100
                 sb.fit(7);
                 for (int kc = 0; kc < kKC; ++kc) {
                     for (int j = 0; j < 7; ++j)
@@ -759,6 +798,11 @@ static void build_stream(const Dims& d, const dygnn_dygformer_weights* w, Stream
                 if (j + 1 < 7) sb.fit(13);
             }
         }
+        sb.fit(1);
+        sb.put_vec(L.out_proj_bias, 0, kD);
+        sb.fit(2);
+        sb.put_vec(L.norm1_weight, 0, kD);
+        sb.put_vec(L.norm1_bias, 0, kD);
         sb.align26();
         for (int p = 0; p < 25; ++p) {
             for (int kc = 0; kc < kKC; ++kc)
@@ -766,13 +810,22 @@ static void build_stream(const Dims& d, const dygnn_dygformer_weights* w, Stream
             for (int u = 0; u < 2; ++u)
                 for (int i = 0; i < kNT; ++i) sb.put(L.ffn1_weight, kHid, 16 * i, kD, 16 * (2 * p + u), kHid);
         }
+        sb.fit(1);
+        sb.put_vec(L.ffn1_bias, 0, kD);
     }
+}
+
+// fragments that do not travel through the ring (read by one wave each): the output layer [tile][k-chunk]
+static void build_aux(const Dims& d, const dygnn_dygformer_weights* w, StreamBuilder& sb) {
+    const int ntile = (d.Fn + 15) / 16;
+    for (int jt = 0; jt < ntile; ++jt)
+        for (int kc = 0; kc < kKC; ++kc) sb.put(w->output_w, kD, 16 * jt, d.Fn, 16 * kc, kD);
 }
 
 struct PackLayout3 {       // float offsets relative to PackedLayout.fused3
     size_t bias_x;
-    struct L { size_t ln, bqkv, bo, b1, b2; } layer[DYGNN_MAX_LAYERS];
-    size_t stream; int64_t nfrag; int nstages;
+    size_t stream; int64_t nfrag; int nstages;     // ring stream: nfrag fragments, padded to whole stages (+ one of slack)
+    size_t aux; int64_t naux;                      // output-layer fragments, directly after the stream
     size_t desc;           // FragDesc table (device copy), 8-byte aligned
     size_t total;
 };
@@ -784,6 +837,7 @@ static int64_t stream_frags(const Dims& d) {
     w.proj_node_w = w.proj_edge_w = w.proj_time_w = w.proj_cooc_w = &dummy;
     dygnn_encoder_layer_weights lw{};
     lw.in_proj_weight = lw.out_proj_weight = lw.ffn0_weight = lw.ffn1_weight = &dummy;
+    lw.in_proj_bias = lw.out_proj_bias = lw.ffn1_bias = lw.norm0_weight = lw.norm0_bias = lw.norm1_weight = lw.norm1_bias = &dummy;
     for (int l = 0; l < d.NL; ++l) w.layers[l] = lw;
     StreamBuilder sb;
     int nchunk[4];
@@ -796,14 +850,12 @@ static PackLayout3 make_layout3(const Dims& d) {
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~size_t(63); return r; };
     f.bias_x = take(kDP);
-    for (int l = 0; l < d.NL; ++l) {
-        auto& L = f.layer[l];
-        L.ln = take(4 * kDP); L.bqkv = take(2 * 3 * 112); L.bo = take(kDP); L.b1 = take(kHid); L.b2 = take(kDP);
-    }
     f.nfrag = stream_frags(d);
     f.nstages = (int)((f.nfrag + kStage - 1) / kStage);
     f.stream = take((size_t)(f.nstages + 1) * kStage * kFrag);
-    f.desc = take(((size_t)f.nfrag * sizeof(FragDesc) + 3) / 4);
+    f.naux = (int64_t)((d.Fn + 15) / 16) * kKC;
+    f.aux = take((size_t)f.naux * kFrag);
+    f.desc = take(((size_t)(f.nfrag + f.naux) * sizeof(FragDesc) + 3) / 4);
     f.total = o;
     return f;
 }
@@ -831,27 +883,19 @@ int pack(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w
     const float* pb[4] = {w->proj_node_b, w->proj_edge_b, w->proj_time_b, w->proj_cooc_b};
     for (int ch = 0; ch < 4; ++ch)
         if (int rc = pack_vec(pb[ch], kC, 0, base + f.bias_x, kC * ch, kC, s)) return rc;
-    for (int l = 0; l < d.NL; ++l) {
-        const dygnn_encoder_layer_weights& L = w->layers[l];
-        const auto& F = f.layer[l];
-        const float* ln[4] = {L.norm0_weight, L.norm0_bias, L.norm1_weight, L.norm1_bias};
-        for (int i = 0; i < 4; ++i)
-            if (int rc = pack_vec(ln[i], kD, 0, base + F.ln, i * kDP, kDP, s)) return rc;
-        for (int h = 0; h < 2; ++h)
-            for (int part = 0; part < 3; ++part)       // head rows 100h .. 100h+99 of the q/k/v bias, zero padded to 112
-                if (int rc = pack_vec(L.in_proj_bias, kHD, part * kD + kHD * h, base + F.bqkv, (h * 3 + part) * 112, 112, s)) return rc;
-        if (int rc = pack_vec(L.out_proj_bias, kD, 0, base + F.bo, 0, kDP, s)) return rc;
-        if (int rc = pack_vec(L.ffn0_bias, kHid, 0, base + F.b1, 0, kHid, s)) return rc;
-        if (int rc = pack_vec(L.ffn1_bias, kD, 0, base + F.b2, 0, kDP, s)) return rc;
-    }
     StreamBuilder sb;
     int nchunk[4];
     build_stream(d, w, sb, nchunk);
     if ((int64_t)sb.frags.size() != f.nfrag) { set_error("pack: stream builder mismatch"); return DYGNN_E_INVALID; }
+    StreamBuilder aux;
+    build_aux(d, w, aux);
+    if ((int64_t)aux.frags.size() != f.naux) { set_error("pack: aux builder mismatch"); return DYGNN_E_INVALID; }
     FragDesc* ddesc = reinterpret_cast<FragDesc*>(base + f.desc);
     DYGNN_HIP(hipMemcpyAsync(ddesc, sb.frags.data(), sb.frags.size() * sizeof(FragDesc), hipMemcpyHostToDevice, s));
-    const int64_t total = f.nfrag * kFrag;
-    hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, ddesc, f.nfrag, base + f.stream);
+    DYGNN_HIP(hipMemcpyAsync(ddesc + f.nfrag, aux.frags.data(), aux.frags.size() * sizeof(FragDesc), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.nfrag * kFrag, 256)), dim3(256), 0, s, ddesc, f.nfrag, base + f.stream);
+    DYGNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.naux * kFrag, 256)), dim3(256), 0, s, ddesc + f.nfrag, f.naux, base + f.aux);
     DYGNN_LAUNCH_CHECK();
     DYGNN_HIP(hipStreamSynchronize(s));     // the descriptor table is copied from this call's host vector
     return DYGNN_OK;
@@ -887,11 +931,10 @@ int forward_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_
     a.stream = base + f.stream; a.nstages = f.nstages;
     a.bias_x = base + f.bias_x;
     for (int l = 0; l < d.NL; ++l) {
-        const auto& F = f.layer[l];
-        LayerP& L = a.layer[l];
-        L.ln = base + F.ln; L.bqkv = base + F.bqkv; L.bo = base + F.bo; L.b1 = base + F.b1; L.b2 = base + F.b2;
+        a.layer[l].b1 = w->layers[l].ffn0_bias;
         a.tap_layer[l] = taps ? taps->layer_out[l] : nullptr;
     }
+    a.outfrag = base + f.aux;
     a.outT = packed + pl.outputT; a.outb = w->output_b;
     a.out_src = out_src; a.out_dst = out_dst;
     a.tap_enc = taps ? taps->encoder_input : nullptr;

@@ -21,7 +21,7 @@ model = DyGFormer(nf, ef, sampler, 100, 50, patch_size=2, num_layers=2, num_head
                   max_input_sequence_length=64, device=dev)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
 model = model.to(dev).eval()
-model.impl = 2
+model.impl = int(os.environ.get("PHASE_IMPL", "3"))
 E = data.num_interactions
 NG = int(os.environ.get("PHASE_GROUPS", "16"))     # groups of 200 pairs per launch (bench default: 16)
 sl = slice(E - 200 * NG, E)
@@ -34,6 +34,15 @@ with torch.no_grad():
     model.compute_src_dst_node_temporal_embeddings(src, dst, t, _taps=taps, _group_size=200)
 torch.cuda.synchronize()
 st = taps["phase_cycles"].cpu().numpy().astype(np.int64)      # [4 wg][8 waves][32]
+if model.impl == 3:
+    cats = ["windows+counts", "projection", "layernorm", "QKV (+K/V store)", "barrier after K/V", "attention (S,softmax,PV)",
+            "out-projection", "FFN", "mean+output layer", "misc (param copies, taps)", "pool shuffles", "pool barrier"]
+    tot = st[:, :, 31].astype(np.float64)
+    print(f"total ticks per wave: mean {tot.mean():.0f} (min {tot.min():.0f} max {tot.max():.0f})")
+    for i, nm in enumerate(cats):
+        v = st[:, :, i].astype(np.float64)
+        print(f"{nm:28s} {v.mean():12.0f} {100 * v.mean() / tot.mean():6.1f}%   (per-wave min {v.min():.0f} max {v.max():.0f})")
+    sys.exit(0)
 NL = 2
 names = ["zero+windows+counts", "projection", "barrier"]
 for l in range(NL):
