@@ -64,6 +64,20 @@ __device__ __forceinline__ void dma_frag(const float* gsrc_lane, float* lds_dst_
                                      (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
 }
 
+// sum over the 16 lanes of a DPP row (= the 16 tokens of a tile, lane & 15), result in every lane: four VALU adds with
+// DPP operands (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror) instead of four LDS bpermutes
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+
 // cos for the time encoder and erf for GELU: same functions as dygformer_fused.hip (see the derivations there)
 __device__ __forceinline__ float cos_time(float x) {
     if (!(fabsf(x) <= 3.0e7f)) return cosf(x);
@@ -107,6 +121,10 @@ struct Args {
     const int32_t* hist_len; const int64_t* end_pos; const CallDims* cd;
     const float *node_feat, *edge_feat, *time_w, *time_b, *lut;
     const float* stream; int nstages;
+    const float* projw;           // projection fragments in step order [node | time | edge | cooc chunks][4 tiles]
+    int proj_frags;               // total projection fragments
+    int slab_chunks;              // k-chunks (steps) per LDS slab
+    int scr_floats;               // LDS floats reserved for the window arrays (the slab follows)
     const float* bias_x;          // [208] projection biases in model-dim order
     const float* outfrag;         // output layer as fragments [ceil(Fn/16) tiles][13 k-chunks]
     LayerP layer[DYGNN_MAX_LAYERS];
@@ -170,13 +188,13 @@ struct WStream {
 // Diagnostic build (-DDYGNN_STAMPS): every wave accumulates s_memtime ticks per phase category and the last four
 // workgroups of the grid store them: taps.phase_cycles[wg][wave][cat]; cat 31 = total.
 #ifdef DYGNN_STAMPS
-#define TDECL unsigned long long tacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tk_ = __builtin_amdgcn_s_memtime(); const unsigned long long tk0_ = tk_
+#define TDECL unsigned long long tacc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tk_ = __builtin_amdgcn_s_memtime(); const unsigned long long tk0_ = tk_
 #define TACC(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc_[i] += t_ - tk_; tk_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define TSTORE()                                                                                   \
     do {                                                                                           \
         if (a.stamps != nullptr && lane == 0 && blockIdx.x + 4 >= gridDim.x) {                     \
             unsigned long long* o_ = a.stamps + ((size_t)(blockIdx.x + 4 - gridDim.x) * 8 + wave) * 32;   \
-            for (int i_ = 0; i_ < 12; ++i_) o_[i_] = tacc_[i_];                                    \
+            for (int i_ = 0; i_ < 16; ++i_) o_[i_] = tacc_[i_];                                    \
             o_[31] = tk_ - tk0_;                                                                   \
         }                                                                                          \
     } while (0)
@@ -185,7 +203,7 @@ struct WStream {
 #define TACC(i) do { } while (0)
 #define TSTORE() do { } while (0)
 #endif
-enum { T_WIN = 0, T_PROJ, T_LN, T_QKV, T_QKVBAR, T_ATTN, T_OPROJ, T_FFN, T_POOL, T_MISC, T_POOL1, T_POOL2 };
+enum { T_WIN = 0, T_PROJ, T_LN, T_QKV, T_QKVBAR, T_ATTN, T_OPROJ, T_FFN, T_POOL, T_MISC, T_POOL1, T_POOL2, T_PNODE, T_PTIME, T_PEDGE, T_PCOOC };
 
 // LayerNorm of the register-resident X^T (two-pass, biased variance, eps 1e-5); gamma/beta from LDS
 __device__ __forceinline__ void layernorm(f4 (&xn)[kNT], const f4 (&x)[kNT], const float* gamma, const float* beta, int g) {
@@ -282,17 +300,26 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
     const bool active = 16 * tt < T;             // wave-uniform: this token tile holds real tokens
     const int tokbase = pi * (16 * TPW);         // this pair's first K/V row
 
-    // ---- zero K, V, slack and misc once (rows of absent tokens are read as MFMA operands and must be finite)
-    for (int i = tid; i < kLdsRing / 4; i += 512) reinterpret_cast<f4*>(lds)[i] = zero4();
-    for (int i = tid; i < kMiscFloats / 4; i += 512) reinterpret_cast<f4*>(lds + kLdsMisc)[i] = zero4();
+    // ---- weights start moving at once: the first four stages of the layer stream into the ring, the first slab of
+    // projection fragments into the K/V region behind the window arrays (all of it lands during the window phase)
     WStream ws;
-    ws.open(a.stream, lds + kLdsRing, lane, wave, a.nstages);      // the first four stages fly during the window phase
+    ws.open(a.stream, lds + kLdsRing, lane, wave, a.nstages);
     const float* ringl = lds + kLdsRing + lane * 4;
-    __syncthreads();
+    float* slab = lds + a.scr_floats;
+    const float* slabl = slab + lane * 4;
+    const int slab_frags = 4 * a.slab_chunks;
+    auto load_slab = [&](int k) {
+        const int f0 = k * slab_frags;
+        const int n = a.proj_frags - f0 < slab_frags ? a.proj_frags - f0 : slab_frags;
+        for (int f = wave; f < n; f += 8) dma_frag(a.projw + (size_t)(f0 + f) * kFrag + lane * 4, slab + (size_t)f * kFrag);
+    };
+    load_slab(0);
+    float* tws = lds + kLdsMisc + kMiscFloats;      // time-encoder w | b
+    for (int i = tid; i < 2 * a.Ft; i += 512) tws[i] = i < a.Ft ? a.time_w[i] : a.time_b[i - a.Ft];
 
     // ---- windows (pad_sequences, DyGFormer.py:228-245): per-pair arrays in the (still unused) K/V region.
     // src positions at [0, Ss), dst positions at [SsA, SsA + Sd); alignment gaps hold id -1 (matches nothing).
-    int32_t* ids = reinterpret_cast<int32_t*>(lds) + pi * (kScratchFloats / NP);
+    int32_t* ids = reinterpret_cast<int32_t*>(lds) + pi * (a.scr_floats / NP);
     int32_t* eids = ids + SA;
     float* dts = reinterpret_cast<float*>(eids + SA);
     int32_t* c0 = reinterpret_cast<int32_t*>(dts + SA);
@@ -339,6 +366,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
             c0[p] = cs; c1[p] = cdn;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of slab 0 and of the first ring stages has landed
     __syncthreads();
 
     TACC(T_WIN);
@@ -348,56 +376,132 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
     for (int i = 0; i < kNT; ++i) x[i] = ldg4(a.bias_x + 16 * i + 4 * g);
 
     // ---- patch projection (DyGFormer.py:148-157): channel ch writes model rows 50ch..50ch+49 = tiles (50ch)/16 .. +3.
-    // One stream step = one 16-wide k-chunk x 4 tiles.  The B operand is gathered straight from the feature tables
-    // (two chunks ahead); (pp, f) = (patch position, feature) of this lane's k are advanced incrementally.
+    // One step = one 16-wide k-chunk x 4 tiles; the fragments of up to slab_chunks steps sit in an LDS slab (loaded by
+    // LDS-DMA, all waves use the same ones), so inside a slab nothing synchronises and the B operand — gathered straight
+    // from the feature tables, (pp, f) = (patch position, feature) of this lane's k advanced incrementally — runs
+    // eight chunks ahead.  Channel order node, time, edge, cooc: the edge gathers are issued before the time channel
+    // computes its cosines, the node gathers before the co-occurrence counts.
     {
         const int tok = 16 * tt + c;
         const bool tv = tok < T;
         const int pos0 = tv ? (tok < Ts ? tok * a.P : SsA + (tok - Ts) * a.P) : 0;
         const int P = a.P;
-        struct Cursor { int pp, f; };
-        auto step_cursor = [](Cursor& cu, int F) { cu.f += 16; if (cu.f >= F) { cu.f -= F; ++cu.pp; } };
-        auto project = [&](auto LOCAL0, int nchunk, int F, auto bfn) {
+        constexpr int DQ = 8;
+        // (pp, f) = patch position and feature of this lane's k; row = the table row of that position, re-read from
+        // LDS only when pp moves on (once per ~11 chunks), so the gather address never waits for an LDS round trip
+        struct Cursor { int pp, f, row; };
+        int sstep = 0, next_slab = 1;
+        // fragments of the next step (all waves call this in lock-step); *fresh: a new slab was loaded for it
+        auto slab_step = [&](bool& fresh) -> const float* {
+            fresh = false;
+            if (sstep == a.slab_chunks) {
+                __syncthreads();                            // everyone is done with the slab
+                load_slab(next_slab++);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                sstep = 0;
+                fresh = true;
+            }
+            return slabl + (size_t)(sstep++) * 4 * kFrag;
+        };
+        auto row_of = [&](const int32_t* idx, int pp) -> int {
+            if (!tv || pp >= P) return -1;
+            const int32_t r = idx[pos0 + pp];
+            return r < 0 ? 0 : r;
+        };
+        auto gather = [&](const float* table, int F, const Cursor& cu) -> f4 {
+            if (cu.row < 0) return zero4();
+            return ldg4(table + (size_t)cu.row * F + cu.f);                                          // DyGFormer.py:259-261
+        };
+        auto step_gather = [&](Cursor& cu, const int32_t* idx, int F) {
+            cu.f += 16;
+            if (cu.f >= F) { cu.f -= F; ++cu.pp; cu.row = row_of(idx, cu.pp); }
+        };
+        // one projection step: fragments of this step in fa[PAR] (read now if `first`/fresh), those of the next step of
+        // the same channel and slab are read into fa[PAR^1] while this step multiplies
+        auto mma_step = [&](auto LOCAL0, const int PR, f4 (&fa)[2][4], bool first, bool more, const f4 bcur) {
             constexpr int L0 = decltype(LOCAL0)::value;
-            Cursor cu{0, 4 * g};
-            f4 b0 = zero4(), b1 = zero4(), b2 = zero4();
+            bool fresh;
+            const float* fr = slab_step(fresh);
             if (active) {
-                b0 = bfn(cu); step_cursor(cu, F);
-                b1 = bfn(cu); step_cursor(cu, F);
-            }
-            for (int kc = 0; kc < nchunk; ++kc) {
-                if (active) {
-                    b2 = bfn(cu); step_cursor(cu, F);           // chunk kc+2 (zeros beyond the patch)
-                    f4 fa[4];
+                if (first || fresh) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) fa[u] = lds4(ringl + (ws.pos + u) * kFrag);
-                    mma_group<4>(&x[L0], fa, b0);
-                    b0 = b1; b1 = b2;
+                    for (int v = 0; v < 4; ++v) fa[PR][v] = lds4(fr + v * kFrag);
                 }
-                ws.advance(4);                                  // 52 = 13 steps of 4: never straddles the ring end
+                if (more && sstep < a.slab_chunks) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) fa[PR ^ 1][v] = lds4(fr + (4 + v) * kFrag);
+                }
+                __builtin_amdgcn_sched_barrier(0);          // operand loads of later steps stay issued ABOVE this step's MFMAs
+                mma_group<4>(&x[L0], fa[PR], bcur);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
-        auto gather = [&](const float* table, const int32_t* idx, int F) {
-            return [=](const Cursor& cu) -> f4 {
-                if (!tv || cu.pp >= P) return zero4();
-                int32_t r = idx[pos0 + cu.pp];
-                r = r < 0 ? 0 : r;
-                return ldg4(table + (size_t)r * F + cu.f);                                           // DyGFormer.py:259-261
-            };
+        // gathered channel: bq[] holds the operands of the next DQ chunks
+        auto prefill = [&](f4 (&bq)[DQ], Cursor& cu, const float* table, const int32_t* idx, int F) {
+            cu = Cursor{0, 4 * g, row_of(idx, 0)};
+            if (active) {
+#pragma unroll
+                for (int u = 0; u < DQ; ++u) { bq[u] = gather(table, F, cu); step_gather(cu, idx, F); }
+            }
         };
-        auto timef = [&](const Cursor& cu) -> f4 {
-            if (!tv || cu.pp >= P || ids[pos0 + cu.pp] <= 0) return zero4();                         // DyGFormer.py:266
-            const float dt = dts[pos0 + cu.pp];
-            const f4 w = ldg4(a.time_w + cu.f), bb = ldg4(a.time_b + cu.f);
-            f4 r;
-            r.x = cos_time(fmaf(dt, w.x, bb.x)); r.y = cos_time(fmaf(dt, w.y, bb.y));
-            r.z = cos_time(fmaf(dt, w.z, bb.z)); r.w = cos_time(fmaf(dt, w.w, bb.w));
+        auto run_gathered = [&](auto LOCAL0, f4 (&bq)[DQ], Cursor& cu, int nchunk, const float* table, const int32_t* idx, int F) {
+            f4 fa[2][4];
+            for (int kc0 = 0; kc0 < nchunk; kc0 += DQ) {
+#pragma unroll
+                for (int u = 0; u < DQ; ++u) {
+                    if (kc0 + u < nchunk) {
+                        const f4 bcur = bq[u];
+                        if (active) { bq[u] = gather(table, F, cu); step_gather(cu, idx, F); }   // chunk kc0+u+DQ (zeros beyond the patch)
+                        mma_step(LOCAL0, u & 1, fa, kc0 + u == 0, kc0 + u + 1 < nchunk, bcur);
+                    }
+                }
+            }
+        };
+        // computed channel (time encoding, co-occurrence features): operands made DC chunks ahead (the LUT reads of the
+        // co-occurrence features are L2 round trips)
+        constexpr int DC = 4;
+        auto run_computed = [&](auto LOCAL0, int nchunk, auto bfn) {
+            f4 br[DC];
+            f4 fa[2][4];
+            if (active) {
+#pragma unroll
+                for (int u = 0; u < DC; ++u) br[u] = bfn();
+            }
+            for (int kc0 = 0; kc0 < nchunk; kc0 += DC) {
+#pragma unroll
+                for (int u = 0; u < DC; ++u) {
+                    if (kc0 + u < nchunk) {
+                        const f4 bcur = br[u];
+                        if (active) br[u] = bfn();
+                        mma_step(LOCAL0, u & 1, fa, kc0 + u == 0, kc0 + u + 1 < nchunk, bcur);
+                    }
+                }
+            }
+        };
+        // time encoding: (valid, dt) of the current patch position are cached like the gather row
+        struct TCur { int pp, f; float dt; bool ok; };
+        auto tpos = [&](TCur& tc) {
+            tc.ok = tv && tc.pp < P && ids[pos0 + tc.pp] > 0;                                        // DyGFormer.py:266
+            tc.dt = tc.ok ? dts[pos0 + tc.pp] : 0.f;
+        };
+        TCur tc{0, 4 * g, 0.f, false};
+        tpos(tc);
+        auto timef = [&]() -> f4 {
+            f4 r = zero4();
+            if (tc.ok) {
+                const f4 w = lds4(tws + tc.f), bb = lds4(tws + a.Ft + tc.f);
+                r.x = cos_time(fmaf(tc.dt, w.x, bb.x)); r.y = cos_time(fmaf(tc.dt, w.y, bb.y));
+                r.z = cos_time(fmaf(tc.dt, w.z, bb.z)); r.w = cos_time(fmaf(tc.dt, w.w, bb.w));
+            }
+            tc.f += 16;
+            if (tc.f >= a.Ft) { tc.f -= a.Ft; ++tc.pp; tpos(tc); }
             return r;
         };
         // co-occurrence features: k = 50*pp + j is not 4-aligned per position, so every element finds its own (pp, j);
         // k/50 by multiply-shift (exact for k < 12000)
         int kco = 4 * g;
-        auto coocf = [&](const Cursor&) -> f4 {
+        auto coocf = [&]() -> f4 {
             f4 r;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -413,15 +517,24 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
             kco += 16;
             return r;
         };
-        ws.fit(4);
-        project(std::integral_constant<int, 0>{}, a.nchunk[0], a.Fn, gather(a.node_feat, ids, a.Fn));
-        project(std::integral_constant<int, 3>{}, a.nchunk[1], a.Fe, gather(a.edge_feat, eids, a.Fe));
-        project(std::integral_constant<int, 6>{}, a.nchunk[2], a.Ft, timef);
-        project(std::integral_constant<int, 9>{}, a.nchunk[3], 1 << 30, coocf);
+        f4 bq[DQ];
+        Cursor cu;
+        prefill(bq, cu, a.node_feat, ids, a.Fn);
+        TACC(T_PROJ);
+        run_gathered(std::integral_constant<int, 0>{}, bq, cu, a.nchunk[0], a.node_feat, ids, a.Fn);
+        prefill(bq, cu, a.edge_feat, eids, a.Fe);            // in flight while the time channel runs
+        TACC(T_PNODE);
+        run_computed(std::integral_constant<int, 6>{}, a.nchunk[2], timef);
+        TACC(T_PTIME);
+        run_gathered(std::integral_constant<int, 3>{}, bq, cu, a.nchunk[1], a.edge_feat, eids, a.Fe);
+        TACC(T_PEDGE);
+        run_computed(std::integral_constant<int, 9>{}, a.nchunk[3], coocf);
+        TACC(T_PCOOC);
     }
     TACC(T_PROJ);
-    __syncthreads();     // everyone is done with the window arrays
-    for (int i = tid; i < kScratchFloats / 4; i += 512) reinterpret_cast<f4*>(lds)[i] = zero4();
+    __syncthreads();     // everyone is done with the window arrays and the slab
+    // K, V and the slack behind them: rows of absent tokens are read as MFMA operands and must be finite
+    for (int i = tid; i < kLdsRing / 4; i += 512) reinterpret_cast<f4*>(lds)[i] = zero4();
     tap_store<TPW>(x, a.tap_enc, b, a.Tmax, T, tt, c, g);
 
     float* Kb = lds + kLdsK;
@@ -673,13 +786,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
             f4 vs = in_src ? x[i] : zero4();
             f4 vd = in_dst ? x[i] : zero4();
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    vs[r] += __shfl_xor(vs[r], o, 64);
-                    vd[r] += __shfl_xor(vd[r], o, 64);
-                }
-            }
+            for (int r = 0; r < 4; ++r) { vs[r] = row_sum16(vs[r]); vd[r] = row_sum16(vd[r]); }
             if (c == 0) {
                 *reinterpret_cast<f4*>(pool + (wave * 2 + 0) * kDP + 16 * i + 4 * g) = vs;
                 *reinterpret_cast<f4*>(pool + (wave * 2 + 1) * kDP + 16 * i + 4 * g) = vd;
@@ -767,15 +874,8 @@ struct StreamBuilder {
 };
 
 static void build_stream(const Dims& d, const dygnn_dygformer_weights* w, StreamBuilder& sb, int (&nchunk)[4]) {
-    const float* pw[4] = {w->proj_node_w, w->proj_edge_w, w->proj_time_w, w->proj_cooc_w};
     const int K[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * d.C};
-    sb.fit(4);
-    for (int ch = 0; ch < 4; ++ch) {
-        nchunk[ch] = (K[ch] + 15) / 16;
-        const int t0 = (kC * ch) / 16;
-        for (int kc = 0; kc < nchunk[ch]; ++kc)
-            for (int u = 0; u < 4; ++u) sb.put(pw[ch], K[ch], 16 * (t0 + u) - kC * ch, kC, 16 * kc, K[ch]);
-    }
+    for (int ch = 0; ch < 4; ++ch) nchunk[ch] = (K[ch] + 15) / 16;
     for (int l = 0; l < d.NL; ++l) {
         const dygnn_encoder_layer_weights& L = w->layers[l];
         sb.fit(2);
@@ -815,6 +915,18 @@ static void build_stream(const Dims& d, const dygnn_dygformer_weights* w, Stream
     }
 }
 
+// projection fragments in step order (channels node, time, edge, cooc; 4 tiles per k-chunk), staged by slabs
+static void build_proj(const Dims& d, const dygnn_dygformer_weights* w, StreamBuilder& sb) {
+    const float* pw[4] = {w->proj_node_w, w->proj_edge_w, w->proj_time_w, w->proj_cooc_w};
+    const int K[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * d.C};
+    const int order[4] = {0, 2, 1, 3};
+    for (int o = 0; o < 4; ++o) {
+        const int ch = order[o], t0 = (kC * ch) / 16;
+        for (int kc = 0; kc < (K[ch] + 15) / 16; ++kc)
+            for (int u = 0; u < 4; ++u) sb.put(pw[ch], K[ch], 16 * (t0 + u) - kC * ch, kC, 16 * kc, K[ch]);
+    }
+}
+
 // fragments that do not travel through the ring (read by one wave each): the output layer [tile][k-chunk]
 static void build_aux(const Dims& d, const dygnn_dygformer_weights* w, StreamBuilder& sb) {
     const int ntile = (d.Fn + 15) / 16;
@@ -825,7 +937,9 @@ static void build_aux(const Dims& d, const dygnn_dygformer_weights* w, StreamBui
 struct PackLayout3 {       // float offsets relative to PackedLayout.fused3
     size_t bias_x;
     size_t stream; int64_t nfrag; int nstages;     // ring stream: nfrag fragments, padded to whole stages (+ one of slack)
-    size_t aux; int64_t naux;                      // output-layer fragments, directly after the stream
+    size_t aux; int64_t naux;                      // output-layer fragments
+    size_t proj; int64_t nproj;                    // projection fragments
+    int scr_floats, slab_chunks;                   // LDS split of the K/V region during the prologue
     size_t desc;           // FragDesc table (device copy), 8-byte aligned
     size_t total;
 };
@@ -855,17 +969,25 @@ static PackLayout3 make_layout3(const Dims& d) {
     f.stream = take((size_t)(f.nstages + 1) * kStage * kFrag);
     f.naux = (int64_t)((d.Fn + 15) / 16) * kKC;
     f.aux = take((size_t)f.naux * kFrag);
-    f.desc = take(((size_t)(f.nfrag + f.naux) * sizeof(FragDesc) + 3) / 4);
+    const int K[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * d.C};
+    f.nproj = 0;
+    for (int ch = 0; ch < 4; ++ch) f.nproj += 4 * (int64_t)((K[ch] + 15) / 16);
+    f.proj = take((size_t)f.nproj * kFrag);
+    f.desc = take(((size_t)(f.nfrag + f.naux + f.nproj) * sizeof(FragDesc) + 3) / 4);
+    const int np = d.Tmax <= 64 ? 2 : 1;
+    f.scr_floats = np * 5 * 2 * ((d.Smax + 3) & ~3);
+    f.slab_chunks = (kScratchFloats - f.scr_floats) / (4 * kFrag);
     f.total = o;
     return f;
 }
 
 bool supported(const Dims& d) {
     if (!(d.C == kC && d.H == 2 && d.Fn % 4 == 0 && d.Fe % 4 == 0 && d.Ft % 4 == 0 && d.Fn >= 16 && d.Fe >= 16 && d.Ft >= 16 &&
-          d.Fn <= 512 && d.NL <= DYGNN_MAX_LAYERS && d.Tmax <= 128)) return false;
+          d.Fn <= 512 && d.NL <= DYGNN_MAX_LAYERS && d.Tmax <= 128 && (kLdsMisc + kMiscFloats + 2 * d.Ft) * 4 <= kLdsBytes)) return false;
     const int np = d.Tmax <= 64 ? 2 : 1;
     // window arrays: 5 x (2 sides, each padded to a multiple of 4) ints per pair in the K/V region; k/50 multiply-shift range
-    return (size_t)np * 5 * (2 * (size_t)((d.Smax + 3) & ~3)) <= (size_t)kScratchFloats && d.P * kC < 12000;
+    // ... and behind them at least 8 k-chunks of projection fragments
+    return (size_t)np * 5 * (2 * (size_t)((d.Smax + 3) & ~3)) + 8 * 4 * kFrag <= (size_t)kScratchFloats && d.P * kC < 12000;
 }
 
 size_t packed_floats(const Dims& d) { return supported(d) ? make_layout3(d).total : 0; }
@@ -893,6 +1015,13 @@ int pack(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w
     FragDesc* ddesc = reinterpret_cast<FragDesc*>(base + f.desc);
     DYGNN_HIP(hipMemcpyAsync(ddesc, sb.frags.data(), sb.frags.size() * sizeof(FragDesc), hipMemcpyHostToDevice, s));
     DYGNN_HIP(hipMemcpyAsync(ddesc + f.nfrag, aux.frags.data(), aux.frags.size() * sizeof(FragDesc), hipMemcpyHostToDevice, s));
+    StreamBuilder pj;
+    build_proj(d, w, pj);
+    if ((int64_t)pj.frags.size() != f.nproj) { set_error("pack: projection builder mismatch"); return DYGNN_E_INVALID; }
+    DYGNN_HIP(hipMemcpyAsync(ddesc + f.nfrag + f.naux, pj.frags.data(), pj.frags.size() * sizeof(FragDesc), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.nproj * kFrag, 256)), dim3(256), 0, s, ddesc + f.nfrag + f.naux, f.nproj,
+                       base + f.proj);
+    DYGNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.nfrag * kFrag, 256)), dim3(256), 0, s, ddesc, f.nfrag, base + f.stream);
     DYGNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.naux * kFrag, 256)), dim3(256), 0, s, ddesc + f.nfrag, f.naux, base + f.aux);
@@ -935,6 +1064,7 @@ int forward_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_
         a.tap_layer[l] = taps ? taps->layer_out[l] : nullptr;
     }
     a.outfrag = base + f.aux;
+    a.projw = base + f.proj; a.proj_frags = (int)f.nproj; a.slab_chunks = f.slab_chunks; a.scr_floats = f.scr_floats;
     a.outT = packed + pl.outputT; a.outb = w->output_b;
     a.out_src = out_src; a.out_dst = out_dst;
     a.tap_enc = taps ? taps->encoder_input : nullptr;

@@ -36,7 +36,7 @@ torch.cuda.synchronize()
 st = taps["phase_cycles"].cpu().numpy().astype(np.int64)      # [4 wg][8 waves][32]
 if model.impl == 3:
     cats = ["windows+counts", "projection", "layernorm", "QKV (+K/V store)", "barrier after K/V", "attention (S,softmax,PV)",
-            "out-projection", "FFN", "mean+output layer", "misc (param copies, taps)", "pool shuffles", "pool barrier"]
+            "out-projection", "FFN", "mean+output layer", "misc (param copies, taps)", "pool shuffles", "pool barrier", "proj node", "proj time", "proj edge", "proj cooc"]
     tot = st[:, :, 31].astype(np.float64)
     print(f"total ticks per wave: mean {tot.mean():.0f} (min {tot.min():.0f} max {tot.max():.0f})")
     for i, nm in enumerate(cats):
