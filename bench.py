@@ -59,7 +59,7 @@ def parse_args():
     ap.add_argument("--workload", default="wikipedia", choices=list(WORKLOADS))
     ap.add_argument("--impl", type=int, default=0, help="0 auto, 1 generic kernels, 2 fused kernel (wave-pair), 3 fused kernel (token-owner)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the launches are issued on (round-robin)")
-    ap.add_argument("--fuse-steps", type=int, default=8,
+    ap.add_argument("--fuse-steps", type=int, default=32,
                     help="steps per launch: the positive and negative calls of F consecutive steps (2F independently "
                          "padded groups of `batch` pairs) form ONE grid, so 256 CUs stay busy instead of 200")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the CPU-baseline sample (0 = skip)")
@@ -211,7 +211,7 @@ def main():
                    "steps_per_launch": F},
         "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                     "kernel": "k_dygformer_fused (+ the 3 tiny window-search launches in front of it)",
+                     "kernel": ("k_dygformer_fused" if args.impl == 2 else "k_dygformer_fused3<4>") + " (+ the 3 tiny window-search launches in front of it)",
                      "flop_per_launch": flop_per_launch, "ms_per_launch": round(launch_ms, 4),
                      "pairs_per_launch": 2 * steps_per_launch * B},
         "mean_auc": round(float(acc[0] / max(acc[2], 1)), 4),

@@ -137,7 +137,7 @@ extern "C" int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg, const 
         return DYGNN_E_UNSUPPORTED;
     }
     auto fn = forward_generic;
-    if (impl == 3) fn = forward_fused3;
+    if (impl == 3 || (impl == 0 && can_fuse3)) fn = forward_fused3;          // auto: token-owner kernel first
     else if (impl == 2 || (impl == 0 && can_fuse)) fn = forward_fused;
     return fn(d, pl, w, static_cast<const float*>(packed), csr, node_feat, edge_feat, src, dst, times, batch, group_size, out_src, out_dst,
               static_cast<char*>(workspace), wl, taps, as_stream(stream));

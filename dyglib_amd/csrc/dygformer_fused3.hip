@@ -109,7 +109,11 @@ __device__ __forceinline__ float erf_as(float x) {
     const float e = __expf(-ax * ax);
     return copysignf(fmaf(-p * t, e, 1.0f), x);
 }
+#ifdef DYGNN_ABLATE_GELU      // timing experiment only (wrong results): what the FFN costs without its activation
+__device__ __forceinline__ float gelu_erf(float v) { return v; }
+#else
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f)); }
+#endif
 
 struct LayerP {
     const float* b1;      // [800]; every other per-layer vector travels in the weight stream

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void k(const float* __restrict__ w, float* 
 
 // MODE 4: NB stage buffers, DMA issued two stages ahead, first operands of the next stage prefetched BEFORE the barrier,
 // GELU of the previous tile pair spread over the A stage of the next one (software pipelined).
-template <int NB, bool PIPE_GELU, bool BARRIER>
+template <int NB, bool PIPE_GELU, bool BARRIER, bool ILV = false>
 __global__ __launch_bounds__(512, 2) void k4(const float* __restrict__ w, float* out, int reps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -180,10 +180,20 @@ __global__ __launch_bounds__(512, 2) void k4(const float* __restrict__ w, float*
                     for (int v = 0; v < 4; ++v) fs[0][v] = lds4(nbuf + (size_t)v * kFrag);       // first group of the B stage
                 }
                 if ((kc & 3) == 0) issue_part(st + 2, kc >> 2);
+                if (ILV) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kc < 8) h[kc >> 2][kc & 3] = gelu_fast(h[kc >> 2][kc & 3]);
+                    mma_group<2>(hn, sa[cur], xn[kc]);
+                    // 8 x { 1 MFMA, 3 VALU }: the GELU of the previous tile pair issues in the shadow of this wave's own MFMAs
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
                 if (PIPE_GELU && kc < 8) h[kc >> 2][kc & 3] = gelu_fast(h[kc >> 2][kc & 3]);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_group<2>(hn, sa[cur], xn[kc]);
                 __builtin_amdgcn_sched_barrier(0);
+                }
             }
             if (!PIPE_GELU) {
 #pragma unroll
@@ -227,15 +237,15 @@ __global__ __launch_bounds__(512, 2) void k4(const float* __restrict__ w, float*
     for (int u = 0; u < 13; ++u) s += y[u].x + y[u].y + y[u].z + y[u].w;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s + ha[0].x + hb[1].y;
 }
-template <int NB, bool PG, bool BAR> void run4(const float* w, const char* name, int blocks) {
+template <int NB, bool PG, bool BAR, bool ILV = false> void run4(const float* w, const char* name, int blocks) {
     const int reps = 40, threads = 512, ldsb = 160 * 1024;
     float* out;
     CK(hipMalloc(&out, blocks * threads * 4));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k4<NB, PG, BAR>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k4<NB, PG, BAR, ILV>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((k4<NB, PG, BAR>), dim3(blocks), dim3(threads), ldsb, 0, w, out, reps);
+    hipLaunchKernelGGL((k4<NB, PG, BAR, ILV>), dim3(blocks), dim3(threads), ldsb, 0, w, out, reps);
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((k4<NB, PG, BAR>), dim3(blocks), dim3(threads), ldsb, 0, w, out, reps);
+    hipLaunchKernelGGL((k4<NB, PG, BAR, ILV>), dim3(blocks), dim3(threads), ldsb, 0, w, out, reps);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -275,6 +285,6 @@ int main() {
     run4<3, false, true>(w, "k4: 3 buffers, prefetch over barrier", 256);
     run4<3, true, true>(w, "k4: 3 buffers, prefetch, pipelined GELU", 256);
     run4<3, true, false>(w, "k4: same, NO barriers (racy; upper bound)", 256);
-    run4<4, true, true>(w, "k4: 4 buffers, prefetch, pipelined GELU", 256);
+    run4<3, true, true, true>(w, "k4: 3 buffers, GELU interleaved by sched_group_barrier", 256);
     return 0;
 }
