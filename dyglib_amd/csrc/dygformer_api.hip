@@ -69,6 +69,54 @@ __global__ __launch_bounds__(256) void k_merge_sigmoid(const float* __restrict__
     }
 }
 
+// The same head on the matrix cores: one wave = 16 rows.  Transposed product H^T[n][m] = sum_k W1[n][k] cat(a,b)[m][k]
+// (A operand = fc1 rows, B operand = the row's features, both K-contiguous float4 reads), four hidden tiles at a time;
+// relu, the fc2 dot product and the sigmoid are applied to the accumulators.  Needs dim % 4 == 0.
+using mf4 = __attribute__((ext_vector_type(4))) float;
+__global__ __launch_bounds__(256) void k_merge_sigmoid_mfma(const float* __restrict__ a, const float* __restrict__ b, int64_t n_rows, int dim,
+                                                              int hidden, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                              const float* __restrict__ w2, const float* __restrict__ b2,
+                                                              float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+    if (m0 >= n_rows) return;
+    const int64_t m = m0 + c;
+    const bool mv = m < n_rows;
+    const int K = 2 * dim;
+    float z = 0.f;
+    for (int n0 = 0; n0 < hidden; n0 += 64) {
+        mf4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = mf4{0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            const int kk = k0 + 4 * g;
+            mf4 bf = mf4{0.f, 0.f, 0.f, 0.f};
+            if (mv && kk < K) bf = kk < dim ? *reinterpret_cast<const mf4*>(a + m * dim + kk) : *reinterpret_cast<const mf4*>(b + m * dim + (kk - dim));
+            mf4 af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + 16 * i + c;
+                af[i] = (n < hidden && kk < K) ? *reinterpret_cast<const mf4*>(w1 + (size_t)n * K + kk) : mf4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[t], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * i + 4 * g + r;
+                if (n < hidden) z = fmaf(fmaxf(acc[i][r] + b1[n], 0.f), w2[n], z);
+            }
+    }
+    z += __shfl_xor(z, 16, 64);
+    z += __shfl_xor(z, 32, 64);
+    if (g == 0 && mv) out[m] = 1.0f / (1.0f + expf(-(z + b2[0])));
+}
+
 }  // namespace dygnn
 
 using namespace dygnn;
@@ -149,6 +197,12 @@ extern "C" int dygnn_merge_layer_sigmoid(const float* a, const float* b, int64_t
     DYGNN_REQUIRE(n >= 0 && dim > 0 && hidden > 0, "merge_layer: bad sizes");
     DYGNN_REQUIRE(n == 0 || (a && b && fc1_w && fc1_b && fc2_w && fc2_b && out), "merge_layer: null pointer");
     if (n == 0) return DYGNN_OK;
+    if (dim % 4 == 0) {
+        hipLaunchKernelGGL(k_merge_sigmoid_mfma, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, as_stream(stream), a, b, n, dim, hidden,
+                           fc1_w, fc1_b, fc2_w, fc2_b, out);
+        DYGNN_LAUNCH_CHECK();
+        return DYGNN_OK;
+    }
     const size_t lds = (size_t)(2 * dim + 4) * sizeof(float);
     DYGNN_REQUIRE(lds <= 64 * 1024, "merge_layer: dim too large");
     hipLaunchKernelGGL(k_merge_sigmoid, dim3((unsigned)n), dim3(256), lds, as_stream(stream), a, b, dim, hidden, fc1_w, fc1_b, fc2_w,
