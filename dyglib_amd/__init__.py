@@ -9,7 +9,7 @@ The compute lives in dyglib_amd/csrc (C ABI: include/dygnn.h).  There is no CPU 
 from .synthetic import InteractionData  # noqa: F401
 
 __all__ = ["DyGFormer", "TGAT", "MemoryModel", "MergeLayer", "TimeEncoder", "NeighborSampler", "get_neighbor_sampler", "TemporalCSR",
-           "count_nodes_appearances", "InteractionData"]
+           "count_nodes_appearances", "InteractionData", "Data", "get_link_prediction_data"]
 
 
 def __getattr__(name):
@@ -29,6 +29,9 @@ def __getattr__(name):
     if name in ("NeighborSampler", "get_neighbor_sampler", "count_nodes_appearances"):
         from . import neighbor_sampler
         return getattr(neighbor_sampler, name)
+    if name in ("Data", "get_link_prediction_data"):
+        from . import data_loader
+        return getattr(data_loader, name)
     if name == "TemporalCSR":
         from .temporal_csr import TemporalCSR
         return TemporalCSR

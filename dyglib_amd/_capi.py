@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported first: see module docstring)
 from . import _build
 
 DYGNN_MAX_LAYERS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -87,6 +87,8 @@ SIGNATURES = {
                                               C.c_void_p]),
     "dygnn_sample_recent": (C.c_int, [C.POINTER(Csr), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
+    "dygnn_gather_selected": (C.c_int, [C.POINTER(Csr), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
     "dygnn_window_lengths": (C.c_int, [C.POINTER(Csr), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "dygnn_window_fill": (C.c_int, [C.POINTER(Csr), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,

@@ -89,6 +89,24 @@ __global__ __launch_bounds__(256) void k_sample_recent(CsrView g, const int64_t*
     }
 }
 
+// gather of host-drawn samples (utils/utils.py:192-199): one thread per output slot
+__global__ __launch_bounds__(256) void k_gather_selected(CsrView g, const int64_t* __restrict__ nodes, const int32_t* __restrict__ sel,
+                                                           int64_t total, int32_t k, int64_t* __restrict__ out_nbr,
+                                                           int64_t* __restrict__ out_eid, float* __restrict__ out_ts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int32_t j = sel[i];
+    int64_t nb = 0, ed = 0;
+    float t = 0.0f;
+    if (j >= 0) {
+        int64_t lo, hi;
+        query_row(g, nodes[i / k], lo, hi);
+        const int64_t p = lo + j;
+        if (p < hi) { nb = g.nbr[p]; ed = g.eid[p]; t = (float)g.ts[p]; }
+    }
+    out_nbr[i] = nb; out_eid[i] = ed; out_ts[i] = t;
+}
+
 __global__ __launch_bounds__(256) void k_window_fill(CsrView g, const int64_t* __restrict__ nodes,
                                                        const double* __restrict__ times, int64_t n, int32_t L, int32_t S,
                                                        const int32_t* __restrict__ hist_len, const int64_t* __restrict__ end_pos,
@@ -150,6 +168,19 @@ extern "C" int dygnn_sample_recent(const dygnn_csr* csr, const int64_t* nodes, c
     const int wpb = 4;
     hipLaunchKernelGGL(k_sample_recent, dim3((unsigned)ceil_div(n, wpb)), dim3(wpb * kWave), 0, as_stream(stream), view(csr),
                        nodes, times, n, k, out_nbr, out_eid, out_ts);
+    DYGNN_LAUNCH_CHECK();
+    return DYGNN_OK;
+}
+
+extern "C" int dygnn_gather_selected(const dygnn_csr* csr, const int64_t* nodes, const int32_t* sel, int64_t n, int32_t k,
+                                     int64_t* out_nbr, int64_t* out_eid, float* out_ts, dygnn_stream_t stream) {
+    if (int rc = check_csr(csr)) return rc;
+    DYGNN_REQUIRE(k > 0, "Number of sampled neighbors for each node should be greater than 0!");     // utils/utils.py:157
+    DYGNN_REQUIRE(n >= 0 && (n == 0 || (nodes && sel && out_nbr && out_eid && out_ts)), "gather_selected: bad arguments");
+    if (n == 0) return DYGNN_OK;
+    const int64_t total = n * k;
+    hipLaunchKernelGGL(k_gather_selected, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), view(csr), nodes, sel,
+                       total, k, out_nbr, out_eid, out_ts);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }

@@ -2,10 +2,11 @@
 (utils/utils.py:71-302) backed by the gfx950 kernels behind include/dygnn.h.
 
 Same constructor, method names, argument meaning, return dtypes and error behaviour as the
-reference for the `recent` strategy and for `get_all_first_hop_neighbors`; `uniform` and
-`time_interval_aware` sampling (host MT19937 replay) are not built yet and raise
-NotImplementedError when sampling is requested (construction and first-hop queries still work,
-which is all DyGFormer needs).
+reference.  `recent` sampling and `get_all_first_hop_neighbors` run entirely on the GPU.  `uniform`
+and `time_interval_aware` (utils/utils.py:176-199, :112-128) must consume the sampler's numpy
+RandomState in batch-row order to stay bit-identical to the reference, so for those two the GPU
+does the time searches and the final gather while the draws, the float32 time lookup and the
+(unstable) argsort of every row are replayed on the host with numpy itself.
 """
 from __future__ import annotations
 
@@ -40,8 +41,23 @@ class NeighborSampler:
         self.device = torch.device(device) if device is not None else _default_device()
         self._lib = _capi.load()
         self._host64 = None
+        if self.sample_neighbor_strategy == "time_interval_aware":
+            # utils/utils.py:105-107: per node, probabilities over its whole time-sorted history
+            self.nodes_neighbor_sampled_probabilities = [
+                self.compute_sampled_probabilities(csr.ts[csr.indptr[v]:csr.indptr[v + 1]]) for v in range(csr.num_nodes)]
         if self.seed is not None:
             self.random_state = np.random.RandomState(self.seed)          # utils/utils.py:109-110
+
+    def compute_sampled_probabilities(self, node_neighbor_times: np.ndarray):
+        """utils/utils.py:112-128, the same numpy float64 operations in the same order."""
+        if len(node_neighbor_times) == 0:
+            return np.array([])
+        node_neighbor_times = node_neighbor_times - np.max(node_neighbor_times)
+        exp_node_neighbor_times = np.exp(self.time_scaling_factor * node_neighbor_times)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            sampled_probabilities = exp_node_neighbor_times / np.cumsum(exp_node_neighbor_times)
+        sampled_probabilities[np.isnan(sampled_probabilities)] = -1e10
+        return sampled_probabilities
 
     # ---- helpers -------------------------------------------------------------------------------
     def _queries_to_device(self, node_ids, node_interact_times) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -57,15 +73,37 @@ class NeighborSampler:
             self._host64 = (self.csr.nbr.astype(np.int64), self.csr.eid.astype(np.int64))
         return self._host64
 
+    def _check_strategy(self):
+        if self.sample_neighbor_strategy not in ("recent", "uniform", "time_interval_aware"):
+            # utils/utils.py:211
+            raise ValueError(f"Not implemented error for sample_neighbor_strategy {self.sample_neighbor_strategy}!")
+
     def _require_recent(self):
-        if self.sample_neighbor_strategy == "recent":
-            return
-        if self.sample_neighbor_strategy in ("uniform", "time_interval_aware"):
+        """The fused TGAT / TGN forwards sample on the device, which only the stateless `recent` strategy allows."""
+        self._check_strategy()
+        if self.sample_neighbor_strategy != "recent":
             raise NotImplementedError(
-                f"sample_neighbor_strategy '{self.sample_neighbor_strategy}' is not built yet on the HIP path "
-                "(SURVEY.md §8f-3); use 'recent'")
-        # utils/utils.py:211
-        raise ValueError(f"Not implemented error for sample_neighbor_strategy {self.sample_neighbor_strategy}!")
+                f"the fused TGAT/TGN forward samples on the device and supports sample_neighbor_strategy 'recent' only; "
+                f"'{self.sample_neighbor_strategy}' is available through NeighborSampler.get_historical_neighbors")
+
+    def _draw_host(self, node_ids_host: np.ndarray, hist_len_host: np.ndarray, k: int) -> np.ndarray:
+        """The reference's per-row draw (utils/utils.py:176-199) replayed with numpy: returns sel [n,k] int32 =
+        positions inside each node's row in FINAL order (after the argsort of the float32 times), -1 = no history."""
+        sel = np.full((len(node_ids_host), k), -1, dtype=np.int32)
+        tia = self.sample_neighbor_strategy == "time_interval_aware"
+        indptr, ts = self.csr.indptr, self.csr.ts
+        rng = self.random_state if self.seed is not None else np.random
+        for idx, (node, cnt) in enumerate(zip(node_ids_host.tolist(), hist_len_host.tolist())):
+            if cnt <= 0:
+                continue
+            p = None
+            if tia:
+                probs = self.nodes_neighbor_sampled_probabilities[node][:cnt]
+                p = torch.softmax(torch.from_numpy(probs).float(), dim=0).numpy()          # utils/utils.py:184
+            sampled = rng.choice(a=cnt, size=k, p=p)                                        # utils/utils.py:186-188
+            t32 = ts[indptr[node] + sampled].astype(np.float32)                             # utils/utils.py:192 (float32 row)
+            sel[idx] = sampled[t32.argsort()]                                               # utils/utils.py:196-199
+        return sel
 
     # ---- device-resident API (no host round trip) ----------------------------------------------
     def hist_len_device(self, nodes: torch.Tensor, times: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -79,12 +117,22 @@ class NeighborSampler:
         return hist, end
 
     def get_historical_neighbors_device(self, nodes: torch.Tensor, times: torch.Tensor, num_neighbors: int = 20):
-        """`recent` sampling on device tensors; returns device tensors ([n,k] int64, int64, float32)."""
-        self._require_recent()
+        """Sampling on device tensors; returns device tensors ([n,k] int64, int64, float32).  `recent` stays on the
+        device; the random strategies make one host round trip (hist_len down, selected positions up)."""
+        self._check_strategy()
         n, k = nodes.numel(), int(num_neighbors)
         out_n = torch.empty((n, max(k, 0)), dtype=torch.int64, device=self.device)
         out_e = torch.empty_like(out_n)
         out_t = torch.empty((n, max(k, 0)), dtype=torch.float32, device=self.device)
+        if self.sample_neighbor_strategy != "recent":
+            assert k > 0, "Number of sampled neighbors for each node should be greater than 0!"
+            hist, _ = self.hist_len_device(nodes, times)
+            sel = self._draw_host(nodes.cpu().numpy(), hist.cpu().numpy(), k)
+            sel_d = torch.from_numpy(sel).to(self.device)
+            rc = self._lib.dygnn_gather_selected(self.csr.on_device(self.device), nodes.data_ptr(), sel_d.data_ptr(), n, k,
+                                                 out_n.data_ptr(), out_e.data_ptr(), out_t.data_ptr(), _capi.current_stream_ptr())
+            _capi.check(rc)
+            return out_n, out_e, out_t
         rc = self._lib.dygnn_sample_recent(self.csr.on_device(self.device), nodes.data_ptr(), times.data_ptr(), n, k,
                                            out_n.data_ptr(), out_e.data_ptr(), out_t.data_ptr(), _capi.current_stream_ptr())
         _capi.check(rc)                                    # k <= 0 -> AssertionError, utils/utils.py:157
@@ -93,19 +141,17 @@ class NeighborSampler:
     # ---- reference API (numpy in, numpy out) ---------------------------------------------------
     def find_neighbors_before(self, node_id: int, interact_time: float, return_sampled_probabilities: bool = False):
         """utils/utils.py:130-147 for a single query (views into the host copy of the CSR)."""
-        if return_sampled_probabilities:
-            raise NotImplementedError("time_interval_aware sampling probabilities are not built yet (SURVEY.md §8f-3)")
         nodes, times = self._queries_to_device(np.array([node_id]), np.array([interact_time]))
         hist, _ = self.hist_len_device(nodes, times)
         i = int(hist.cpu()[0])
         a = int(self.csr.indptr[node_id])
         n64, e64 = self._host_rows64()
-        return n64[a:a + i], e64[a:a + i], self.csr.ts[a:a + i], None
+        probs = self.nodes_neighbor_sampled_probabilities[node_id][:i] if return_sampled_probabilities else None
+        return n64[a:a + i], e64[a:a + i], self.csr.ts[a:a + i], probs
 
     def get_historical_neighbors(self, node_ids: np.ndarray, node_interact_times: np.ndarray, num_neighbors: int = 20):
-        """utils/utils.py:149-214 (strategy 'recent'): ndarrays [n,k] int64, int64, float32."""
+        """utils/utils.py:149-214: ndarrays [n,k] int64, int64, float32."""
         assert num_neighbors > 0, "Number of sampled neighbors for each node should be greater than 0!"
-        self._require_recent()
         nodes, times = self._queries_to_device(node_ids, node_interact_times)
         n, e, t = self.get_historical_neighbors_device(nodes, times, num_neighbors)
         return n.cpu().numpy(), e.cpu().numpy(), t.cpu().numpy()
@@ -114,7 +160,6 @@ class NeighborSampler:
                                 num_neighbors: int = 20):
         """utils/utils.py:216-252; hop h>1 queries use the float32 times returned by hop h-1."""
         assert num_hops > 0, "Number of sampled hops should be greater than 0!"
-        self._require_recent()
         nodes, times = self._queries_to_device(node_ids, node_interact_times)
         B = nodes.numel()
         n, e, t = self.get_historical_neighbors_device(nodes, times, num_neighbors)

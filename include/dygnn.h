@@ -77,6 +77,14 @@ int dygnn_find_neighbors_before(const dygnn_csr* csr_host, const int64_t* nodes,
 int dygnn_sample_recent(const dygnn_csr* csr_host, const int64_t* nodes, const double* times, int64_t n, int32_t k,
                         int64_t* out_nbr, int64_t* out_eid, float* out_ts, dygnn_stream_t stream);
 
+/* get_historical_neighbors, strategies 'uniform' / 'time_interval_aware' (utils/utils.py:176-199): the draws come
+ * from the host (numpy RandomState replay, so they are bit-identical to the reference's), this entry point gathers
+ * them: sel [n,k] int32 holds, per query, the positions INSIDE the node's time-sorted row (0 = oldest interaction) in
+ * final output order, or -1 for "no neighbour" (rows of nodes without history stay zero, utils/utils.py:161-167).
+ * Outputs [n,k]: int64 ids, int64 edge ids, float32 times. */
+int dygnn_gather_selected(const dygnn_csr* csr_host, const int64_t* nodes, const int32_t* sel, int64_t n, int32_t k,
+                          int64_t* out_nbr, int64_t* out_eid, float* out_ts, dygnn_stream_t stream);
+
 /* DyGFormer window, phase 1 (get_all_first_hop_neighbors utils/utils.py:254-273 + the length
  * scan of pad_sequences models/DyGFormer.py:210-220): per query hist_len / end_pos as above and
  * *max_window = max_q min(hist_len[q], L-1) (device int32, overwritten).  The padded length is

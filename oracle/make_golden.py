@@ -93,6 +93,53 @@ def run_case(name: str) -> dict:
     return out
 
 
+def run_sampling_case(name: str) -> dict:
+    """uniform / time_interval_aware draws of the reference sampler (utils/utils.py:176-199) on the case's query batch."""
+    c = gc.build_case(name)
+    d = c["data"]
+    ref_data = RefData(d.src_node_ids, d.dst_node_ids, d.node_interact_times, d.edge_ids, d.labels)
+    q_nodes = np.concatenate([c["src"], c["dst"]])
+    q_times = np.concatenate([c["times"], c["times"]])
+    out = {}
+    for tag, (strategy, seed, tsf) in gc.SAMPLING_STRATEGIES.items():
+        sampler = ref_get_neighbor_sampler(ref_data, sample_neighbor_strategy=strategy, time_scaling_factor=tsf, seed=seed)
+        for k in gc.SAMPLING_KS:
+            n, e, t = sampler.get_historical_neighbors(q_nodes, q_times, num_neighbors=k)
+            out[f"{tag}_k{k}_nbr"], out[f"{tag}_k{k}_eid"], out[f"{tag}_k{k}_ts"] = n, e, t
+        nl, el, tl = sampler.get_multi_hop_neighbors(2, q_nodes, q_times, num_neighbors=gc.SAMPLING_HOP_K)
+        for h in range(2):
+            out[f"{tag}_hop{h}_nbr"], out[f"{tag}_hop{h}_eid"], out[f"{tag}_hop{h}_ts"] = nl[h], el[h], tl[h]
+        if strategy == "time_interval_aware":       # probabilities of the busiest node (compute_sampled_probabilities)
+            v = int(np.argmax([len(x) for x in sampler.nodes_neighbor_ids]))
+            out[f"{tag}_prob_node"] = np.array(v)
+            out[f"{tag}_prob"] = np.asarray(sampler.nodes_neighbor_sampled_probabilities[v], dtype=np.float64)
+    out["numpy_version"] = np.array(np.__version__)
+    return out
+
+
+def run_loader_case() -> dict:
+    """the reference's get_link_prediction_data on the synthetic dataset files of tests/golden_cases.py"""
+    import contextlib, io, tempfile, warnings
+    from utils.DataLoader import get_link_prediction_data as ref_get_link_prediction_data      # noqa: E402  (reference)
+    tmp = tempfile.mkdtemp()
+    name = gc.write_dataset_files(tmp)
+    cwd = os.getcwd()
+    os.chdir(tmp)                     # the reference reads ./processed_data/...
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r = ref_get_link_prediction_data(name, gc.LOADER_CASE["val_ratio"], gc.LOADER_CASE["test_ratio"])
+    finally:
+        os.chdir(cwd)
+    out = {"node_feat_shape": np.array(r[0].shape), "edge_feat_shape": np.array(r[1].shape),
+           "node_feat_dtype": np.array(str(r[0].dtype)), "edge_feat_dtype": np.array(str(r[1].dtype)),
+           "edge_feat_sum": np.array(r[1].sum()), "python_version": np.array(sys.version.split()[0])}
+    for tag, d in zip(("full", "train", "val", "test", "new_node_val", "new_node_test"), r[2:]):
+        out[f"{tag}_edge_ids"] = d.edge_ids
+        out[f"{tag}_num_unique_nodes"] = np.array(d.num_unique_nodes)
+    return out
+
+
 def run_tgat_case(name: str) -> dict:
     c = gc.build_tgat_case(name)
     d, cfg = c["data"], c["tgat_cfg"]
@@ -143,8 +190,18 @@ def run_tgn_case(name: str) -> dict:
 def main():
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(8)
-    names = sys.argv[1:] or (list(gc.CASES) + list(gc.TGAT_CASES) + list(gc.TGN_CASES))
+    names = sys.argv[1:] or (list(gc.CASES) + list(gc.TGAT_CASES) + list(gc.TGN_CASES) + ["sampling_" + n for n in gc.SAMPLING_CASES] + ["loader_toy"])
     for name in names:
+        if name == "loader_toy":
+            np.savez_compressed(os.path.join(gc.GOLDEN_DIR, name + ".npz"), **run_loader_case())
+            print(f"{name}: written")
+            continue
+        if name.startswith("sampling_"):
+            out = run_sampling_case(name[len("sampling_"):])
+            path = os.path.join(gc.GOLDEN_DIR, name + ".npz")
+            np.savez_compressed(path, **out)
+            print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+            continue
         if name in gc.TGN_CASES:
             out = run_tgn_case(name)
             path = os.path.join(gc.GOLDEN_DIR, name + ".npz")

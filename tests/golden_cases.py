@@ -54,6 +54,18 @@ TGN_CASES = {
 TAP_ROWS = 3          # intermediates are stored for the first TAP_ROWS rows only
 SAMPLER_KS = (1, 10, 20)
 
+# random sampling strategies (utils/utils.py:176-199): fixtures `sampling_<case>.npz` hold the reference's outputs for this
+# sequence of calls on ONE sampler per strategy (the RandomState carries over from call to call):
+#   get_historical_neighbors(k) for k in SAMPLING_KS, then get_multi_hop_neighbors(2 hops, k = SAMPLING_HOP_K)
+SAMPLING_CASES = ("bip_p2_l64", "hub_p4_l48")
+SAMPLING_KS = (10, 20)
+SAMPLING_HOP_K = 5
+SAMPLING_STRATEGIES = {          # tag -> (strategy, seed, time_scaling_factor)
+    "uniform": ("uniform", 3, 0.0),
+    "tia_soft": ("time_interval_aware", 5, 1e-6),
+    "tia_sharp": ("time_interval_aware", 7, 1e-3),     # exp underflow: the nan -> -1e10 branch of utils/utils.py:127
+}
+
 
 def build_case(name: str):
     """-> dict(data, node_feat, edge_feat, params, mparams, src, dst, neg_dst, times, cfg)"""
@@ -119,3 +131,24 @@ def build_tgn_case(name: str):
                              t=d.node_interact_times[i * B:(i + 1) * B], eid=d.edge_ids[i * B:(i + 1) * B],
                              neg=syn.random_negative_dst(rs, uniq, B)) for i in range(nb)]
     return c
+
+
+# ---- dataset files (reference utils/DataLoader.py:67-168): a synthetic dataset written in the reference's on-disk format
+LOADER_CASE = dict(name="toy", users=60, items=20, edges=3000, graph_seed=5, edge_feat_cols=4, val_ratio=0.15, test_ratio=0.15)
+
+
+def write_dataset_files(root: str) -> str:
+    """processed_data/<name>/ml_<name>.csv (+ .npy, _node.npy) under `root`; returns the dataset name."""
+    from dyglib_amd import synthetic as syn
+    r = LOADER_CASE
+    d = os.path.join(root, "processed_data", r["name"])
+    os.makedirs(d, exist_ok=True)
+    data, nf, ef = syn.make_bipartite_graph(r["users"], r["items"], r["edges"], seed=r["graph_seed"])
+    with open(os.path.join(d, f"ml_{r['name']}.csv"), "w") as f:
+        f.write(",u,i,ts,label,idx\n")
+        for k in range(data.num_interactions):
+            f.write(f"{k},{int(data.src_node_ids[k])},{int(data.dst_node_ids[k])},{float(data.node_interact_times[k])!r},"
+                    f"{float(data.labels[k])!r},{int(data.edge_ids[k])}\n")
+    np.save(os.path.join(d, f"ml_{r['name']}.npy"), ef[:, :r["edge_feat_cols"]])
+    np.save(os.path.join(d, f"ml_{r['name']}_node.npy"), nf)
+    return r["name"]
