@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_tgat_inputs(const float* __restrict__ h
                                                        const float* __restrict__ tw, const float* __restrict__ tb, int64_t n, int k, int Fn, int Fe,
                                                        int Ft, float* __restrict__ kv_in, float* __restrict__ q_in) {
     // row r in [0, n*k): neighbour (i = r / k, j = r % k) = lower-level entry n + r ; rows n*k .. n*k+n-1: the query rows
-    const int64_t r = blockIdx.x;
+    const int64_t r = kv_in ? (int64_t)blockIdx.x : n * k + blockIdx.x;      // kv_in == NULL: query rows only
     const int Kkv = Fn + Fe + Ft, Kq = Fn + Ft;
     if (r < n * k) {
         const int64_t le = n + r;
@@ -96,6 +96,158 @@ __global__ __launch_bounds__(256) void k_tgat_inputs(const float* __restrict__ h
         const float* hsrc = h_lower ? h_lower + i * Fn : node_feat + (size_t)lower_ids[i] * Fn;
         float* o = q_in + i * Kq;
         for (int f = threadIdx.x; f < Kq; f += blockDim.x) o[f] = f < Fn ? hsrc[f] : cosf(fmaf(0.0f, tw[f - Fn], tb[f - Fn]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K/V projection fused with its input gather: kv[r][nb*Dq + :] = W_nb . [h(nbr) | edge | cos(w dt + b)]  (nb = 0 key,
+// 1 value; bias-free, models/modules.py:126-128,150-163), the [n*k][Fn+Fe+Ft] input never exists in memory.
+// One workgroup = 8 waves x 32 rows; wave: 2 row tiles x NT column tiles of accumulators.  Transposed product
+// (A operand = weight fragments, B operand = the row's features): the 17 fragments of a 16-wide k-chunk are shared by
+// all 8 waves, so they are staged through an LDS ring by LDS-DMA (8 k-chunks deep) and every fragment read feeds 8
+// MFMAs; the B operand is gathered straight from the tables / computed (time encoding) four chunks ahead.
+// ------------------------------------------------------------------------------------------------
+constexpr int kKvNT = 17;            // column tiles per workgroup (Dq <= 272)
+constexpr int kKvSlots = 8;          // ring depth in k-chunks
+constexpr int kKvLds = kKvSlots * kKvNT * 1024;
+
+__device__ __forceinline__ float cos_time_t(float x) {      // same range reduction + polynomial as dygformer_fused3.hip
+    if (!(fabsf(x) <= 3.0e7f)) return cosf(x);
+    const float INV_HI = 0.15915493667125702f, INV_LO = 6.4206382432985265e-09f;
+    const float p = x * INV_HI;
+    const float e = fmaf(x, INV_HI, -p);
+    const float q = fmaf(x, INV_LO, e);
+    const float t = (p - rintf(p)) + q;
+    float u = fabsf(t);
+    u = u > 0.5f ? 1.0f - u : u;
+    const bool flip = u > 0.25f;
+    const float v = flip ? 0.5f - u : u;
+    const float z = v * v;
+    float r = fmaf(7.903536371318467f, z, -26.42625678337438f);
+    r = fmaf(r, z, 60.24464137187666f);
+    r = fmaf(r, z, -85.45681720669373f);
+    r = fmaf(r, z, 64.93939402266829f);
+    r = fmaf(r, z, -19.739208802178716f);
+    r = fmaf(r, z, 1.0f);
+    return flip ? -r : r;
+}
+
+// weight fragments [nb][k-chunk][tile][64 lanes x 4]: lane (c,g), element t = W_nb[16 tile + c][16 chunk + 4g + t]
+__global__ void k_pack_kv(const float* __restrict__ wk, const float* __restrict__ wv, int Dq, int Dkv, int KC, float* __restrict__ dst) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)2 * KC * kKvNT * 256;
+    if (idx >= total) return;
+    const int t = idx & 3, lane = (idx >> 2) & 63;
+    const int64_t f = idx >> 8;
+    const int tile = (int)(f % kKvNT), kc = (int)((f / kKvNT) % KC), nb = (int)(f / ((int64_t)kKvNT * KC));
+    const int row = 16 * tile + (lane & 15), col = 16 * kc + 4 * (lane >> 4) + t;
+    const float* w = nb ? wv : wk;
+    dst[idx] = (row < Dq && col < Dkv) ? w[(size_t)row * Dkv + col] : 0.f;
+}
+
+__global__ __launch_bounds__(512, 2) void k_tgat_kv(const float* __restrict__ h_lower, const float* __restrict__ node_feat,
+                                                      const float* __restrict__ edge_feat, const int32_t* __restrict__ lower_ids,
+                                                      const int32_t* __restrict__ nbr_eid, const float* __restrict__ nbr_dt,
+                                                      const float* __restrict__ tw, const float* __restrict__ tb, int64_t n, int k, int Fn, int Fe,
+                                                      int Ft, const float* __restrict__ wfrag, int KC, int Dq, float* __restrict__ kv) {
+    extern __shared__ __attribute__((aligned(16))) float ring[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int nb = blockIdx.y;
+    const int64_t R = n * k;
+    const int64_t m0 = (int64_t)blockIdx.x * 256 + wave * 32;
+    const int Kkv = Fn + Fe + Ft;
+    // this lane's two rows
+    const float* hp[2]; const float* ep[2]; float dt[2]; bool rv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t r = m0 + 16 * j + c;
+        rv[j] = r < R;
+        const int64_t rr = rv[j] ? r : 0;
+        const int64_t le = n + rr;
+        hp[j] = h_lower ? h_lower + le * Fn : node_feat + (size_t)lower_ids[le] * Fn;       // layer 1: raw features
+        ep[j] = edge_feat + (size_t)nbr_eid[rr] * Fe;
+        dt[j] = nbr_dt[rr];
+    }
+    auto fetch = [&](int j, int kc) -> f4 {
+        const int kk = 16 * kc + 4 * g;
+        if (!rv[j] || kk >= Kkv) return f4{0.f, 0.f, 0.f, 0.f};
+        if (kk < Fn) return *reinterpret_cast<const f4*>(hp[j] + kk);
+        if (kk < Fn + Fe) return *reinterpret_cast<const f4*>(ep[j] + (kk - Fn));
+        const int f = kk - Fn - Fe;
+        const f4 w = *reinterpret_cast<const f4*>(tw + f), b = *reinterpret_cast<const f4*>(tb + f);
+        f4 r;
+        r.x = cos_time_t(fmaf(dt[j], w.x, b.x)); r.y = cos_time_t(fmaf(dt[j], w.y, b.y));
+        r.z = cos_time_t(fmaf(dt[j], w.z, b.z)); r.w = cos_time_t(fmaf(dt[j], w.w, b.w));
+        return r;
+    };
+    const float* wsrc = wfrag + (size_t)nb * KC * kKvNT * 256 + lane * 4;
+    auto issue_stage = [&](int s) {        // k-chunk s -> ring slot s % 8; this wave's fragments wave, wave+8, wave+16
+        if (s < KC) {
+            for (int f = wave; f < kKvNT; f += 8)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + ((size_t)s * kKvNT + f) * 256),
+                                                 (__attribute__((address_space(3))) void*)(ring + ((s % kKvSlots) * kKvNT + f) * 256), 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < kKvSlots - 1; ++s) issue_stage(s);
+    constexpr int DB = 4;                  // B operands in flight (k-chunks ahead)
+    f4 bq[DB][2];
+#pragma unroll
+    for (int u = 0; u < DB; ++u) { bq[u][0] = fetch(0, u); bq[u][1] = fetch(1, u); }
+    f4 acc[2][kKvNT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < kKvNT; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
+    const float* rl = ring + lane * 4;
+    for (int kc0 = 0; kc0 < KC; kc0 += DB) {
+#pragma unroll
+        for (int u = 0; u < DB; ++u) {
+            const int kc = kc0 + u;
+            if (kc < KC) {
+                // stage kc was issued >= 7 iterations ago: everything but this wave's youngest operations has landed; the
+                // barrier publishes the stage and frees the slot of stage kc-1 for the DMA issued right after it
+                if (kc + kKvSlots < KC) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // tail: no younger DMAs to count on
+                issue_stage(kc + kKvSlots - 1);
+                const f4 b0 = bq[u][0], b1 = bq[u][1];
+                bq[u][0] = fetch(0, kc + DB); bq[u][1] = fetch(1, kc + DB);
+                const float* fr = rl + (size_t)((kc % kKvSlots) * kKvNT) * 256;
+                f4 fs[2][4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) fs[0][v] = *reinterpret_cast<const f4*>(fr + v * 256);
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {              // tiles 0-3, 4-7, 8-11, 12-15, 16
+                    const int i0 = 4 * q, nn = q < 4 ? 4 : 1;
+                    if (q + 1 < 5) {
+                        const int n2 = q + 1 < 4 ? 4 : 1;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) if (v < n2) fs[(q + 1) & 1][v] = *reinterpret_cast<const f4*>(fr + (4 * (q + 1) + v) * 256);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            if (v < nn) {
+                                acc[0][i0 + v] = tmfma(fs[q & 1][v][t], b0[t], acc[0][i0 + v]);
+                                acc[1][i0 + v] = tmfma(fs[q & 1][v][t], b1[t], acc[1][i0 + v]);
+                            }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    // accumulator tile = kv^T[col = 16i + 4g + r][row = c]: four consecutive columns per lane
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t r = m0 + 16 * j + c;
+        if (r >= R) continue;
+        float* o = kv + (size_t)r * 2 * Dq + (size_t)nb * Dq + 4 * g;
+#pragma unroll
+        for (int i = 0; i < kKvNT; ++i)
+            if (16 * i + 4 * g < Dq) *reinterpret_cast<f4*>(o + 16 * i) = acc[j][i];
     }
 }
 
@@ -238,7 +390,8 @@ struct TgatPlan {
     int64_t n[DYGNN_MAX_LAYERS + 1];       // level sizes: n[L] = 2B, n[l-1] = n[l] * (1 + k)
     // byte offsets
     size_t ids[DYGNN_MAX_LAYERS + 1], times[DYGNN_MAX_LAYERS + 1], eid[DYGNN_MAX_LAYERS + 1], dt[DYGNN_MAX_LAYERS + 1], h[DYGNN_MAX_LAYERS + 1];
-    size_t kv_in, q_in, kv, q, att, fc, merge_in, hid, total;
+    size_t kv_in, q_in, kv, q, att, fc, merge_in, hid, kvw, total;
+    int KC;
 };
 
 static TgatPlan make_tgat_plan(const dygnn_tgat_config& c, int64_t B) {
@@ -257,7 +410,9 @@ static TgatPlan make_tgat_plan(const dygnn_tgat_config& c, int64_t B) {
         p.dt[l] = l >= 1 ? take((size_t)p.n[l] * p.k * sizeof(float)) : 0;
     }
     const int64_t nmax = p.L >= 1 ? p.n[1] : 0;                        // the largest computed level
-    p.kv_in = take((size_t)nmax * p.k * p.Dkv * sizeof(float));
+    p.kv_in = 0;                                                       // the K/V input rows are gathered inside k_tgat_kv
+    p.KC = (p.Dkv + 15) / 16;
+    p.kvw = take((size_t)2 * p.KC * kKvNT * 256 * sizeof(float));      // packed key/value weights of the layer being evaluated
     p.q_in = take((size_t)nmax * p.Dq * sizeof(float));
     p.kv = take((size_t)nmax * p.k * 2 * p.Dq * sizeof(float));
     p.q = take((size_t)nmax * p.Dq * sizeof(float));
@@ -280,6 +435,7 @@ static int check_tgat(const dygnn_tgat_config* c) {
     // utils/utils.py:157
     DYGNN_REQUIRE(c->num_neighbors > 0, "Number of sampled neighbors for each node should be greater than 0!");
     DYGNN_REQUIRE(c->num_neighbors <= 64, "tgat: num_neighbors > 64 not supported");
+    DYGNN_REQUIRE(c->node_feat_dim + c->time_feat_dim <= 16 * 17, "tgat: node_feat_dim + time_feat_dim > 272 not supported");
     return DYGNN_OK;
 }
 
@@ -341,12 +497,23 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
         const dygnn_tgat_layer_weights& Lw = w->layers[l - 1];
         const int64_t n = p.n[l];
         const float* h_lower = l >= 2 ? F32(p.h[l - 1]) : nullptr;
-        hipLaunchKernelGGL(k_tgat_inputs, dim3((unsigned)(n * p.k + n)), dim3(256), 0, s, h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]),
-                           F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, F32(p.kv_in), F32(p.q_in));
+        hipLaunchKernelGGL(k_tgat_inputs, dim3((unsigned)n), dim3(256), 0, s, h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]),
+                           F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, (float*)nullptr, F32(p.q_in));     // query rows
         DYGNN_LAUNCH_CHECK();
-        // K and V projections write the two halves of one [n*k][2*Dq] buffer (bias-free, modules.py:126-128)
-        if (int rc = gemm_nt<false>(F32(p.kv_in), Lw.key_w, nullptr, F32(p.kv), n * p.k, p.Dq, p.Dkv, 2 * p.Dq, s)) return rc;
-        if (int rc = gemm_nt<false>(F32(p.kv_in), Lw.value_w, nullptr, F32(p.kv) + p.Dq, n * p.k, p.Dq, p.Dkv, 2 * p.Dq, s)) return rc;
+        // K and V projections (bias-free, modules.py:126-128) write the two halves of one [n*k][2*Dq] buffer
+        {
+            const int64_t tot = (int64_t)2 * p.KC * kKvNT * 256;
+            hipLaunchKernelGGL(k_pack_kv, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s, Lw.key_w, Lw.value_w, p.Dq, p.Dkv, p.KC, F32(p.kvw));
+            DYGNN_LAUNCH_CHECK();
+            static bool attr_set = false;
+            if (!attr_set) {
+                DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tgat_kv), hipFuncAttributeMaxDynamicSharedMemorySize, kKvLds));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_tgat_kv, dim3((unsigned)ceil_div(n * p.k, 256), 2), dim3(512), kKvLds, s, h_lower, node_feat, edge_feat, I32(p.ids[l - 1]),
+                               I32(p.eid[l]), F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, F32(p.kvw), p.KC, p.Dq, F32(p.kv));
+            DYGNN_LAUNCH_CHECK();
+        }
         if (int rc = gemm_nt<false>(F32(p.q_in), Lw.query_w, nullptr, F32(p.q), n, p.Dq, p.Dq, p.Dq, s)) return rc;
         hipLaunchKernelGGL(k_tgat_attention, dim3((unsigned)ceil_div(n, 4)), dim3(256), (size_t)4 * p.H * p.k * sizeof(float), s, F32(p.q), F32(p.kv),
                            I32(p.ids[l - 1]), n, p.k, p.H, p.hd, scale, F32(p.att));
