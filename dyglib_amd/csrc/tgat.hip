@@ -313,37 +313,58 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ A, co
 // sum of V (models/modules.py:168-191).  q [n][H*hd], kv [n*k][2*H*hd] (K then V), out [n][H*hd]
 __global__ __launch_bounds__(256) void k_tgat_attention(const float* __restrict__ q, const float* __restrict__ kv, const int32_t* __restrict__ lower_ids,
                                                           int64_t n, int k, int H, int hd, float scale, float* __restrict__ out) {
+    // Lanes sweep a key's row as float4 (coalesced): with D = H*hd floats per half, float4 index x < D/4 is the K part,
+    // D/4 <= x < D/2 the V part.  Pass A: scores (per-head wave reductions), softmax; pass B: weighted sum of V, every lane
+    // owning the output float4s of its own column indices.  Needs hd % 4 == 0 and D/4 <= 128.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
     if (i >= n) return;
-    float* pw = reinterpret_cast<float*>(smem) + wave * H * k;       // [H][k] probabilities
-    const int D = H * hd;
-    for (int hj = lane; hj < H * k; hj += kWave) {
-        const int h = hj / k, j = hj % k;
-        const float* qv = q + i * D + h * hd;
-        const float* kvr = kv + (size_t)(i * k + j) * 2 * D + h * hd;
-        float s = 0.f;
-        for (int d = 0; d < hd; ++d) s = fmaf(qv[d], kvr[d], s);
-        s *= scale;                                                   // modules.py:173
-        if (lower_ids[n + i * k + j] == 0) s = -1e10f;                // modules.py:176-184
-        pw[hj] = s;
+    float* pw = reinterpret_cast<float*>(smem) + wave * H * k;       // [H][k] scores -> probabilities
+    const int D = H * hd, D4 = D >> 2, hd4 = hd >> 2;
+    const f4* q4 = reinterpret_cast<const f4*>(q + i * D);
+    // this lane's K columns: x0 = lane, x1 = lane + 64 (when < D4), their heads, and the query values
+    const int x0 = lane, x1 = lane + 64;
+    const bool v0 = x0 < D4, v1 = x1 < D4;
+    const f4 qa = v0 ? q4[x0] : f4{0.f, 0.f, 0.f, 0.f}, qb = v1 ? q4[x1] : f4{0.f, 0.f, 0.f, 0.f};
+    const int h0 = v0 ? x0 / hd4 : -1, h1 = v1 ? x1 / hd4 : -1;
+    for (int j = 0; j < k; ++j) {
+        const f4* row = reinterpret_cast<const f4*>(kv + (size_t)(i * k + j) * 2 * D);
+        float pa = 0.f, pb = 0.f;
+        if (v0) { const f4 kk = row[x0]; pa = fmaf(qa.x, kk.x, fmaf(qa.y, kk.y, fmaf(qa.z, kk.z, qa.w * kk.w))); }
+        if (v1) { const f4 kk = row[x1]; pb = fmaf(qb.x, kk.x, fmaf(qb.y, kk.y, fmaf(qb.z, kk.z, qb.w * kk.w))); }
+        for (int h = 0; h < H; ++h) {
+            float s = (h0 == h ? pa : 0.f) + (h1 == h ? pb : 0.f);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == 0) {
+                s *= scale;                                               // modules.py:173
+                if (lower_ids[n + i * k + j] == 0) s = -1e10f;            // modules.py:176-184
+                pw[h * k + j] = s;
+            }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int h = 0; h < H; ++h) {
+    if (lane < H) {                                                       // softmax over the k keys of head `lane`
         float mx = -INFINITY;
-        for (int j = 0; j < k; ++j) mx = fmaxf(mx, pw[h * k + j]);
+        for (int j = 0; j < k; ++j) mx = fmaxf(mx, pw[lane * k + j]);
         float sum = 0.f;
-        for (int j = 0; j < k; ++j) sum += expf(pw[h * k + j] - mx);
+        for (int j = 0; j < k; ++j) { const float e = expf(pw[lane * k + j] - mx); pw[lane * k + j] = e; sum += e; }
         const float inv = 1.0f / sum;
-        for (int d = lane; d < hd; d += kWave) {
-            float acc = 0.f;
-            for (int j = 0; j < k; ++j)
-                acc = fmaf(expf(pw[h * k + j] - mx) * inv, kv[(size_t)(i * k + j) * 2 * D + D + h * hd + d], acc);
-            out[i * D + h * hd + d] = acc;
-        }
+        for (int j = 0; j < k; ++j) pw[lane * k + j] *= inv;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    f4 oa = f4{0.f, 0.f, 0.f, 0.f}, ob = f4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < k; ++j) {
+        const f4* row = reinterpret_cast<const f4*>(kv + (size_t)(i * k + j) * 2 * D) + D4;     // V half
+        if (v0) { const float p = pw[h0 * k + j]; const f4 vv = row[x0]; oa.x = fmaf(p, vv.x, oa.x); oa.y = fmaf(p, vv.y, oa.y); oa.z = fmaf(p, vv.z, oa.z); oa.w = fmaf(p, vv.w, oa.w); }
+        if (v1) { const float p = pw[h1 * k + j]; const f4 vv = row[x1]; ob.x = fmaf(p, vv.x, ob.x); ob.y = fmaf(p, vv.y, ob.y); ob.z = fmaf(p, vv.z, ob.z); ob.w = fmaf(p, vv.w, ob.w); }
+    }
+    f4* o4 = reinterpret_cast<f4*>(out + i * D);
+    if (v0) o4[x0] = oa;
+    if (v1) o4[x1] = ob;
 }
 
 // y = LayerNorm(fc_out + residual) (models/modules.py:196-199), written into the first Dq columns of the MergeLayer input
@@ -436,6 +457,7 @@ static int check_tgat(const dygnn_tgat_config* c) {
     DYGNN_REQUIRE(c->num_neighbors > 0, "Number of sampled neighbors for each node should be greater than 0!");
     DYGNN_REQUIRE(c->num_neighbors <= 64, "tgat: num_neighbors > 64 not supported");
     DYGNN_REQUIRE(c->node_feat_dim + c->time_feat_dim <= 16 * 17, "tgat: node_feat_dim + time_feat_dim > 272 not supported");
+    DYGNN_REQUIRE(((c->node_feat_dim + c->time_feat_dim) / c->num_heads) % 4 == 0, "tgat: head dim must be a multiple of 4");
     return DYGNN_OK;
 }
 
