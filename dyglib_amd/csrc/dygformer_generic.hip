@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void k_window_lengths2(CsrView2 g, const int64
         hist_len[q] = len;
         end_pos[q] = i;
         CallDims* cd = cds + r / G;
-        atomicMax(is_dst ? &cd->maxw_d : &cd->maxw_s, len < L - 1 ? len : L - 1);
+        int32_t* mw = is_dst ? &cd->maxw_d : &cd->maxw_s;
+        const int32_t v = len < L - 1 ? len : L - 1;
+        if (v > __atomic_load_n(mw, __ATOMIC_RELAXED)) atomicMax(mw, v);      // monotone maximum: most queries skip the atomic
     }
 }
 
