@@ -110,6 +110,12 @@ SIGNATURES = {
     "dygnn_tgn_forward": (C.c_int, [C.POINTER(TgatConfig), C.POINTER(TgatWeights), C.POINTER(GruWeights), C.POINTER(Csr), C.c_void_p, C.c_void_p,
                                     C.POINTER(TgnState), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dygnn_dygformer_train_workspace_bytes": (C.c_size_t, [C.POINTER(DygformerConfig), C.c_int64]),
+    "dygnn_dygformer_train_forward": (C.c_int, [C.POINTER(DygformerConfig), C.POINTER(DygformerWeights), C.POINTER(Csr), C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "dygnn_dygformer_backward": (C.c_int, [C.POINTER(DygformerConfig), C.POINTER(DygformerWeights), C.POINTER(DygformerWeights), C.c_void_p,
+                                           C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dygnn_merge_layer_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

@@ -1,0 +1,647 @@
+// Training path of the DyGFormer hot path: a forward that keeps what the backward pass needs and the
+// backward pass itself, so train_link_prediction.py:229-257 (forward, loss.backward(), optimizer.step()) runs on hand-written
+// HIP kernels.  models/DyGFormer.py:68-194 and :418-461 in train mode: dropout on the attention probabilities
+// (nn.MultiheadAttention(dropout=...), :429), on the attention output and on the FFN (:456-460).
+//
+// Design: activations live in HBM (dense [B*T][.] rows, T = tokens per pair of THIS call), every product is one general
+// fp32-MFMA GEMM kernel (k_mm: any transposition, strided batches for the per-(pair, head) attention products), the rest is
+// row-wise / element-wise kernels.  Dropout masks are not stored: both passes draw them from a counter-based hash of
+// (seed, site, element).  Gradients are produced for every parameter; the feature tables get none (the reference keeps
+// them as constants, models/DyGFormer.py:28-29).
+// This is the first, unfused version (correctness + a working training loop); inference uses dygformer_fused3.hip.
+#include "dygformer_layout.h"
+
+namespace dygnn {
+
+int window_lengths_device(const Dims& d, const dygnn_csr* csr, const int64_t* src, const int64_t* dst, const double* times,
+                          int64_t B, int64_t G, char* ws, const WorkspaceLayout& wl, hipStream_t s);   // dygformer_generic.hip
+
+namespace train {
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+
+// ------------------------------------------------------------------------------------------------
+// C = alpha * op(A) . op(B) (+ bias[n]) (+ beta * C), batched: z = zb * H + zh selects A + zb*sAb + zh*sAh etc.
+//   op(A)[m][k] = transA ? A[k*lda + m] : A[m*lda + k] ;  op(B)[k][n] = transB ? B[n*ldb + k] : B[k*ldb + n]
+// 64x64 tile per workgroup (4 waves x 16 rows x 64 columns), K in steps of 16 through LDS, v_mfma_f32_16x16x4_f32.
+// ------------------------------------------------------------------------------------------------
+struct MM {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K, lda, ldb, ldc, transA, transB;
+    float alpha, beta;
+    int H; int64_t sAb, sAh, sBb, sBh, sCb, sCh;
+};
+
+__global__ __launch_bounds__(256) void k_mm(const MM p) {
+    __shared__ float As[16][64 + 4];
+    __shared__ float Bs[16][64 + 4];
+    const int z = blockIdx.z, zb = z / p.H, zh = z % p.H;
+    const float* A = p.A + zb * p.sAb + zh * p.sAh;
+    const float* Bm = p.B + zb * p.sBb + zh * p.sBh;
+    float* C = p.C + zb * p.sCb + zh * p.sCh;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    f4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.K; k0 += 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e;
+            int m, k;
+            if (p.transA) { m = idx & 63; k = idx >> 6; } else { m = idx >> 4; k = idx & 15; }
+            float v = 0.f;
+            if (m0 + m < p.M && k0 + k < p.K) v = p.transA ? A[(size_t)(k0 + k) * p.lda + m0 + m] : A[(size_t)(m0 + m) * p.lda + k0 + k];
+            As[k][m] = v;
+            int n, kb;
+            if (p.transB) { n = idx >> 4; kb = idx & 15; } else { n = idx & 63; kb = idx >> 6; }
+            float w = 0.f;
+            if (n0 + n < p.N && k0 + kb < p.K) w = p.transB ? Bm[(size_t)(n0 + n) * p.ldb + k0 + kb] : Bm[(size_t)(k0 + kb) * p.ldb + n0 + n];
+            Bs[kb][n] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float a = As[4 * kk + g][16 * wave + c];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[4 * kk + g][16 * nt + c], acc[nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + 16 * nt + c;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * wave + 4 * g + r;
+            if (m >= p.M) continue;
+            float v = p.alpha * acc[nt][r] + bv;
+            if (p.beta != 0.f) v += p.beta * C[(size_t)m * p.ldc + n];
+            C[(size_t)m * p.ldc + n] = v;
+        }
+    }
+}
+
+static int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb, bool tB, float* C, int ldc, int M, int N, int K,
+              const float* bias = nullptr, float alpha = 1.f, float beta = 0.f, int batch = 1, int H = 1, int64_t sAb = 0, int64_t sAh = 0,
+              int64_t sBb = 0, int64_t sBh = 0, int64_t sCb = 0, int64_t sCh = 0) {
+    if (M <= 0 || N <= 0 || batch <= 0) return DYGNN_OK;
+    MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh};
+    hipLaunchKernelGGL(k_mm, dim3((unsigned)ceil_div(M, 64), (unsigned)ceil_div(N, 64), (unsigned)batch), dim3(256), 0, s, p);
+    DYGNN_LAUNCH_CHECK();
+    return DYGNN_OK;
+}
+
+// out[n] (+)= sum_m A[m][n]   (bias gradients); one workgroup per 64 columns
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ A, int lda, int64_t M, int N, float* __restrict__ out, int accumulate) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), r0 = threadIdx.x >> 6;
+    float s = 0.f;
+    if (n < N)
+        for (int64_t m = r0; m < M; m += 4) s += A[m * lda + n];
+    red[r0][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (r0 == 0 && n < N) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        out[n] = accumulate ? out[n] + t : t;
+    }
+}
+static int colsum(hipStream_t s, const float* A, int lda, int64_t M, int N, float* out, bool accumulate = false) {
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)ceil_div(N, 64)), dim3(256), 0, s, A, lda, M, N, out, accumulate ? 1 : 0);
+    DYGNN_LAUNCH_CHECK();
+    return DYGNN_OK;
+}
+
+// ---- dropout: counter-based, identical in forward and backward ----------------------------------------------------
+__device__ __forceinline__ uint32_t rnd32(uint64_t seed, uint32_t site, uint64_t idx) {      // splitmix64 of (seed, site, idx)
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + ((uint64_t)site << 52);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)((z ^ (z >> 31)) >> 20);
+}
+struct Drop {
+    uint64_t seed; uint32_t thresh; float scale;      // keep iff rnd >= thresh; kept values are multiplied by 1/(1-p)
+    __device__ __forceinline__ float mask(uint32_t site, uint64_t idx) const {
+        if (thresh == 0u) return 1.0f;
+        return rnd32(seed, site, idx) >= thresh ? scale : 0.0f;
+    }
+};
+static Drop make_drop(float p, uint64_t seed) {
+    Drop d;
+    d.seed = seed;
+    d.thresh = p <= 0.f ? 0u : (uint32_t)((double)p * 4294967296.0);
+    d.scale = p <= 0.f ? 1.0f : (float)(1.0 / (1.0 - (double)p));
+    return d;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- LayerNorm rows (eps 1e-5, biased variance; models/DyGFormer.py:438-439) ---------------------------------------
+__global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta, int64_t M,
+                                                  int D, float* __restrict__ Y, float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* x = X + row * D;
+    float s = 0.f;
+    for (int k = lane; k < D; k += 64) s += x[k];
+    const float mean = wave_sum(s) / (float)D;
+    float v = 0.f;
+    for (int k = lane; k < D; k += 64) { const float d = x[k] - mean; v = fmaf(d, d, v); }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)D + 1e-5f);
+    for (int k = lane; k < D; k += 64) Y[row * D + k] = (x[k] - mean) * rstd * gamma[k] + beta[k];
+    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+}
+// dX[row] += LN'(dY) ; dgamma += sum dY*xhat ; dbeta += sum dY   (per-workgroup partial sums, then atomics)
+__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean_i,
+                                                  const float* __restrict__ rstd_i, const float* __restrict__ gamma, int64_t M, int D,
+                                                  float* __restrict__ dX, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    extern __shared__ float part[];            // [2][D]
+    for (int k = threadIdx.x; k < 2 * D; k += 256) part[k] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int rr = 0; rr < 16; ++rr) {          // 64 rows per workgroup
+        const int64_t row = (int64_t)blockIdx.x * 64 + rr * 4 + wave;
+        if (row >= M) break;
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = lane; k < D; k += 64) {
+            const float xh = (X[row * D + k] - mean) * rstd, gy = dY[row * D + k] * gamma[k];
+            s1 += gy; s2 = fmaf(gy, xh, s2);
+        }
+        s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
+        for (int k = lane; k < D; k += 64) {
+            const float xh = (X[row * D + k] - mean) * rstd, dy = dY[row * D + k];
+            dX[row * D + k] += rstd * (dy * gamma[k] - s1 - xh * s2);
+            atomicAdd(&part[k], dy * xh);
+            atomicAdd(&part[D + k], dy);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < D; k += 256) { atomicAdd(&dgamma[k], part[k]); atomicAdd(&dbeta[k], part[D + k]); }
+}
+
+// ---- softmax over the keys of one (pair, head, query) row + dropout on the probabilities ---------------------------
+__global__ __launch_bounds__(256) void k_softmax_fwd(const float* __restrict__ S, int64_t rows, int T, Drop dr, uint32_t site,
+                                                       float* __restrict__ P, float* __restrict__ Pd) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* s = S + row * T;
+    float mx = -INFINITY;
+    for (int j = lane; j < T; j += 64) mx = fmaxf(mx, s[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int j = lane; j < T; j += 64) sum += expf(s[j] - mx);
+    const float inv = 1.0f / wave_sum(sum);
+    for (int j = lane; j < T; j += 64) {
+        const float pv = expf(s[j] - mx) * inv;
+        P[row * T + j] = pv;
+        Pd[row * T + j] = pv * dr.mask(site, (uint64_t)row * T + j);
+    }
+}
+// dS = P o (dP - sum_j dP_j P_j), dP = dPd * mask      (in place: dPd -> dS)
+__global__ __launch_bounds__(256) void k_softmax_bwd(float* __restrict__ dPd, const float* __restrict__ P, int64_t rows, int T, Drop dr, uint32_t site) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float dot = 0.f;
+    for (int j = lane; j < T; j += 64) dot = fmaf(dPd[row * T + j] * dr.mask(site, (uint64_t)row * T + j), P[row * T + j], dot);
+    dot = wave_sum(dot);
+    for (int j = lane; j < T; j += 64) {
+        const float dp = dPd[row * T + j] * dr.mask(site, (uint64_t)row * T + j);
+        dPd[row * T + j] = P[row * T + j] * (dp - dot);
+    }
+}
+
+// ---- element-wise pieces ------------------------------------------------------------------------------------------------
+__global__ void k_gelu_drop_fwd(const float* __restrict__ Hpre, int64_t n, Drop dr, uint32_t site, float* __restrict__ Hact) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = Hpre[i];
+    Hact[i] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)) * dr.mask(site, (uint64_t)i);       // F.gelu, DyGFormer.py:458
+}
+__global__ void k_gelu_drop_bwd(float* __restrict__ dH, const float* __restrict__ Hpre, int64_t n, Drop dr, uint32_t site) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = Hpre[i];
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+    dH[i] = dH[i] * dr.mask(site, (uint64_t)i) * (cdf + v * pdf);
+}
+// Xout = Xin + dropout(Y)
+__global__ void k_drop_add_fwd(const float* __restrict__ Xin, const float* __restrict__ Y, int64_t n, Drop dr, uint32_t site, float* __restrict__ Xout) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) Xout[i] = Xin[i] + Y[i] * dr.mask(site, (uint64_t)i);
+}
+// dY = dXout * mask
+__global__ void k_drop_bwd(const float* __restrict__ dXout, int64_t n, Drop dr, uint32_t site, float* __restrict__ dY) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dY[i] = dXout[i] * dr.mask(site, (uint64_t)i);
+}
+
+// ---- embedding inputs: windows, co-occurrence counts, patch matrices -----------------------------------------------------
+struct EmbedArgs {
+    const int64_t* indptr; const int32_t* nbr; const int32_t* eid; const double* ts;
+    const int64_t *src, *dst; const double* times; const int32_t* hist_len; const int64_t* end_pos;
+    const float *node_feat, *edge_feat, *time_w, *time_b, *lut;
+    int64_t B; int Ss, Sd, Ts, T, P, L, Fn, Fe, Ft, C;
+    int32_t *ids, *c0, *c1; float* dts;          // meta [B][S]
+    float *Pn, *Pe, *Pt, *Pc;                    // patch matrices [B*T][P*F]
+};
+__global__ __launch_bounds__(256) void k_embed_inputs(const EmbedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = a.Ss + a.Sd;
+    int32_t* ids = reinterpret_cast<int32_t*>(smem);
+    int32_t* eids = ids + S;
+    float* dts = reinterpret_cast<float*>(eids + S);
+    int32_t* c0 = reinterpret_cast<int32_t*>(dts + S);
+    int32_t* c1 = c0 + S;
+    const int64_t b = blockIdx.x;
+    const double t = a.times[b];
+    for (int p = threadIdx.x; p < S; p += 256) {           // pad_sequences, DyGFormer.py:228-245
+        const bool is_dst = p >= a.Ss;
+        const int j = is_dst ? p - a.Ss : p;
+        const int64_t q = is_dst ? a.B + b : b;
+        const int32_t len = a.hist_len[q];
+        const int32_t m = len < a.L - 1 ? len : a.L - 1;
+        int32_t id = 0, e = 0;
+        float tn = 0.f;
+        if (j == 0) { id = (int32_t)(is_dst ? a.dst[b] : a.src[b]); tn = (float)t; }
+        else if (j <= m) { const int64_t pos = a.end_pos[q] - m + (j - 1); id = a.nbr[pos]; e = a.eid[pos]; tn = (float)a.ts[pos]; }
+        ids[p] = id; eids[p] = e; dts[p] = (float)(t - (double)tn);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < S; p += 256) {           // count_nodes_appearances, DyGFormer.py:337-393
+        const int32_t v = ids[p];
+        int32_t cs = 0, cdn = 0;
+        for (int q = 0; q < a.Ss; ++q) cs += (ids[q] == v);
+        for (int q = a.Ss; q < S; ++q) cdn += (ids[q] == v);
+        if (v == 0) { cs = 0; cdn = 0; }
+        c0[p] = cs; c1[p] = cdn;
+        a.ids[b * S + p] = v; a.dts[b * S + p] = dts[p]; a.c0[b * S + p] = cs; a.c1[b * S + p] = cdn;
+    }
+    __syncthreads();
+    const int Kn = a.P * a.Fn, Ke = a.P * a.Fe, Kt = a.P * a.Ft, Kc = a.P * a.C, Kall = Kn + Ke + Kt + Kc;
+    for (int idx = threadIdx.x; idx < a.T * Kall; idx += 256) {
+        const int tok = idx / Kall;
+        int k = idx - tok * Kall;
+        const int p0 = tok < a.Ts ? tok * a.P : a.Ss + (tok - a.Ts) * a.P;
+        const int64_t row = b * a.T + tok;
+        if (k < Kn) { const int pp = p0 + k / a.Fn; a.Pn[row * Kn + k] = a.node_feat[(size_t)ids[pp] * a.Fn + k % a.Fn]; continue; }
+        k -= Kn;
+        if (k < Ke) { const int pp = p0 + k / a.Fe; a.Pe[row * Ke + k] = a.edge_feat[(size_t)eids[pp] * a.Fe + k % a.Fe]; continue; }
+        k -= Ke;
+        if (k < Kt) {
+            const int pp = p0 + k / a.Ft, f = k % a.Ft;
+            a.Pt[row * Kt + k] = ids[pp] == 0 ? 0.f : cosf(fmaf(dts[pp], a.time_w[f], a.time_b[f]));                 // modules.py:37, DyGFormer.py:266
+            continue;
+        }
+        k -= Kt;
+        { const int pp = p0 + k / a.C, f = k % a.C; a.Pc[row * Kc + k] = a.lut[(size_t)c0[pp] * a.C + f] + a.lut[(size_t)c1[pp] * a.C + f]; }
+    }
+}
+// f(c) = W1 relu(W0 c + b0) + b1 for c = 0 .. rows-1 (DyGFormer.py:332-335); hidden activations kept for the backward pass
+__global__ void k_lut_fwd(const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
+                          int rows, int C, float* __restrict__ lut, float* __restrict__ hid) {
+    const int c = blockIdx.x;
+    extern __shared__ float h[];
+    for (int j = threadIdx.x; j < C; j += blockDim.x) { h[j] = fmaxf(fmaf(w0[j], (float)c, b0[j]), 0.f); hid[c * C + j] = h[j]; }
+    __syncthreads();
+    for (int j = threadIdx.x; j < C; j += blockDim.x) {
+        float acc = b1[j];
+        for (int k = 0; k < C; ++k) acc = fmaf(w1[j * C + k], h[k], acc);
+        lut[c * C + j] = acc;
+    }
+}
+// time-encoder gradients from dPt [M][P*Ft]: pre = w dt + b, d cos = -sin(pre)
+__global__ __launch_bounds__(256) void k_time_bwd(const float* __restrict__ dPt, const int32_t* __restrict__ ids, const float* __restrict__ dts,
+                                                    const float* __restrict__ tw, const float* __restrict__ tb, int64_t B, int Ss, int Sd, int Ts, int T,
+                                                    int P, int Ft, float* __restrict__ dw, float* __restrict__ db) {
+    extern __shared__ float part[];            // [2][Ft]
+    for (int k = threadIdx.x; k < 2 * Ft; k += 256) part[k] = 0.f;
+    __syncthreads();
+    const int S = Ss + Sd, Kt = P * Ft;
+    const int64_t b = blockIdx.x;
+    for (int idx = threadIdx.x; idx < T * Kt; idx += 256) {
+        const int tok = idx / Kt, k = idx - tok * Kt, f = k % Ft;
+        const int pp = (tok < Ts ? tok * P : Ss + (tok - Ts) * P) + k / Ft;
+        if (ids[b * S + pp] == 0) continue;
+        const float dt = dts[b * S + pp];
+        const float gsin = -sinf(fmaf(dt, tw[f], tb[f])) * dPt[(b * T + tok) * Kt + k];
+        atomicAdd(&part[f], gsin * dt);
+        atomicAdd(&part[Ft + f], gsin);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < Ft; k += 256) { atomicAdd(&dw[k], part[k]); atomicAdd(&db[k], part[Ft + k]); }
+}
+// dlut[count][j] += dPc over both count channels (feature = lut[c0] + lut[c1], DyGFormer.py:409-411)
+__global__ __launch_bounds__(256) void k_cooc_bwd(const float* __restrict__ dPc, const int32_t* __restrict__ c0, const int32_t* __restrict__ c1, int64_t B,
+                                                    int Ss, int Sd, int Ts, int T, int P, int C, float* __restrict__ dlut) {
+    const int S = Ss + Sd, Kc = P * C;
+    const int64_t b = blockIdx.x;
+    for (int idx = threadIdx.x; idx < T * Kc; idx += 256) {
+        const int tok = idx / Kc, k = idx - tok * Kc, j = k % C;
+        const int pp = (tok < Ts ? tok * P : Ss + (tok - Ts) * P) + k / C;
+        const float gv = dPc[(b * T + tok) * Kc + k];
+        atomicAdd(&dlut[(size_t)c0[b * S + pp] * C + j], gv);
+        atomicAdd(&dlut[(size_t)c1[b * S + pp] * C + j], gv);
+    }
+}
+// gradients of the co-occurrence MLP from dlut (one workgroup; rows <= a few hundred, C = 50)
+__global__ __launch_bounds__(256) void k_lut_bwd(const float* __restrict__ dlut, const float* __restrict__ hid, const float* __restrict__ w1, int rows, int C,
+                                                   float* __restrict__ dw0, float* __restrict__ db0, float* __restrict__ dw1, float* __restrict__ db1) {
+    // dw1[j][k] = sum_c dlut[c][j] hid[c][k] ; db1[j] = sum_c dlut[c][j] ; dh[c][k] = (hid > 0) sum_j w1[j][k] dlut[c][j]
+    // dw0[k] = sum_c dh[c][k] * c ; db0[k] = sum_c dh[c][k]
+    for (int idx = threadIdx.x; idx < C * C; idx += 256) {
+        const int j = idx / C, k = idx % C;
+        float acc = 0.f;
+        for (int c = 0; c < rows; ++c) acc = fmaf(dlut[c * C + j], hid[c * C + k], acc);
+        dw1[idx] = acc;
+    }
+    for (int j = threadIdx.x; j < C; j += 256) {
+        float acc = 0.f;
+        for (int c = 0; c < rows; ++c) acc += dlut[c * C + j];
+        db1[j] = acc;
+    }
+    for (int k = threadIdx.x; k < C; k += 256) {
+        float aw = 0.f, ab = 0.f;
+        for (int c = 0; c < rows; ++c) {
+            if (hid[c * C + k] > 0.f) {
+                float dh = 0.f;
+                for (int j = 0; j < C; ++j) dh = fmaf(w1[j * C + k], dlut[c * C + j], dh);
+                aw = fmaf(dh, (float)c, aw); ab += dh;
+            }
+        }
+        dw0[k] = aw; db0[k] = ab;
+    }
+}
+
+// pooled[side][b][:] = mean over the side's tokens (DyGFormer.py:181-187)
+__global__ __launch_bounds__(256) void k_pool_fwd(const float* __restrict__ X, int64_t B, int Ts, int T, int D, float* __restrict__ pooled) {
+    const int64_t b = blockIdx.x;
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        const int side = i / D, n = i % D;
+        const int t0 = side ? Ts : 0, t1 = side ? T : Ts;
+        float s = 0.f;
+        for (int t = t0; t < t1; ++t) s += X[(b * T + t) * D + n];
+        pooled[((int64_t)side * B + b) * D + n] = s / (float)(t1 - t0);
+    }
+}
+__global__ void k_pool_bwd(const float* __restrict__ dpooled, int64_t B, int Ts, int T, int D, float* __restrict__ dX) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T * D) return;
+    const int n = (int)(i % D);
+    const int64_t row = i / D, b = row / T;
+    const int t = (int)(row % T);
+    const int side = t >= Ts;
+    dX[i] = dpooled[((int64_t)side * B + b) * D + n] / (float)(side ? T - Ts : Ts);
+}
+
+// ---- workspace -----------------------------------------------------------------------------------------------------------
+struct Plan {
+    WorkspaceLayout wl;       // prefix compatible with window_lengths_device (dims, hist_len, end_pos)
+    size_t ids, dts, c0, c1, lut, hid, Pn, Pe, Pt, Pc, X[DYGNN_MAX_LAYERS + 1];
+    struct L { size_t xn0, m0, r0, qkv, S, P, Pd, oa, ao, x1, xn1, m1, r1, hpre, hact, f2; } layer[DYGNN_MAX_LAYERS];
+    size_t pooled, out, dX, dA, dB, dQKV, dH, dpool, dPt, dPc, dlut, total;
+};
+static Plan make_plan(const Dims& d, int64_t B) {
+    Plan p{};
+    p.wl = make_workspace_layout(d, B);
+    size_t o = (p.wl.end_pos + (size_t)2 * B * sizeof(int64_t) + 255) & ~size_t(255);
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~size_t(255); return r; };
+    const size_t S = 2 * (size_t)d.Smax, M = (size_t)B * d.Tmax, F = sizeof(float);
+    p.ids = take(B * S * 4); p.dts = take(B * S * 4); p.c0 = take(B * S * 4); p.c1 = take(B * S * 4);
+    p.lut = take((size_t)(S + 1) * d.C * F); p.hid = take((size_t)(S + 1) * d.C * F);
+    p.Pn = take(M * d.P * d.Fn * F); p.Pe = take(M * d.P * d.Fe * F); p.Pt = take(M * d.P * d.Ft * F); p.Pc = take(M * d.P * d.C * F);
+    for (int l = 0; l <= d.NL; ++l) p.X[l] = take(M * d.D * F);
+    for (int l = 0; l < d.NL; ++l) {
+        auto& L = p.layer[l];
+        L.xn0 = take(M * d.D * F); L.m0 = take(M * F); L.r0 = take(M * F); L.qkv = take(M * 3 * d.D * F);
+        L.S = take((size_t)B * d.H * d.Tmax * d.Tmax * F); L.P = take((size_t)B * d.H * d.Tmax * d.Tmax * F); L.Pd = take((size_t)B * d.H * d.Tmax * d.Tmax * F);
+        L.oa = take(M * d.D * F); L.ao = take(M * d.D * F); L.x1 = take(M * d.D * F); L.xn1 = take(M * d.D * F); L.m1 = take(M * F); L.r1 = take(M * F);
+        L.hpre = take(M * 4 * d.D * F); L.hact = take(M * 4 * d.D * F); L.f2 = take(M * d.D * F);
+    }
+    p.pooled = take((size_t)2 * B * d.D * F); p.out = take((size_t)2 * B * d.Fn * F);
+    p.dX = take(M * d.D * F); p.dA = take(M * d.D * F); p.dB = take(M * d.D * F); p.dQKV = take(M * 3 * d.D * F); p.dH = take(M * 4 * d.D * F);
+    p.dpool = take((size_t)2 * B * d.D * F); p.dPt = take(M * d.P * d.Ft * F); p.dPc = take(M * d.P * d.C * F); p.dlut = take((size_t)(S + 1) * d.C * F);
+    p.total = o;
+    return p;
+}
+
+static int supported(const Dims& d) {
+    if (d.C <= 0 || d.H <= 0 || d.D % d.H != 0) { set_error("train: bad dims"); return DYGNN_E_INVALID; }
+    if ((size_t)5 * 2 * d.Smax * 4 > 60 * 1024) { set_error("train: max_input_sequence_length too large for the embedding kernel"); return DYGNN_E_UNSUPPORTED; }
+    return DYGNN_OK;
+}
+
+#define EW(kernel, n, ...)                                                                                          \
+    do {                                                                                                            \
+        hipLaunchKernelGGL(kernel, dim3((unsigned)ceil_div((int64_t)(n), 256)), dim3(256), 0, s, __VA_ARGS__);      \
+        DYGNN_LAUNCH_CHECK();                                                                                       \
+    } while (0)
+
+}  // namespace train
+}  // namespace dygnn
+
+using namespace dygnn;
+using namespace dygnn::train;
+
+extern "C" size_t dygnn_dygformer_train_workspace_bytes(const dygnn_dygformer_config* cfg, int64_t batch) {
+    if (check_config(cfg) != DYGNN_OK || batch < 0) return 0;
+    const Dims d = make_dims(*cfg);
+    if (supported(d) != DYGNN_OK) return 0;
+    return make_plan(d, batch).total;
+}
+
+extern "C" int dygnn_dygformer_train_forward(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, const dygnn_csr* csr,
+                                             const float* node_feat, const float* edge_feat, const int64_t* src, const int64_t* dst,
+                                             const double* times, int64_t batch, float dropout_p, uint64_t seed, float* out_src, float* out_dst,
+                                             void* workspace, size_t workspace_bytes, int32_t* seq_lens_host, dygnn_stream_t stream) {
+    if (int rc = check_config(cfg)) return rc;
+    const Dims d = make_dims(*cfg);
+    if (int rc = supported(d)) return rc;
+    DYGNN_REQUIRE(w && csr && csr->indptr && node_feat && edge_feat, "train_forward: null pointer");
+    DYGNN_REQUIRE(batch > 0 && src && dst && times && out_src && out_dst && workspace && seq_lens_host, "train_forward: bad arguments");
+    DYGNN_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "train_forward: dropout must be in [0, 1)");
+    const Plan p = make_plan(d, batch);
+    if (workspace_bytes < p.total) { set_error("train_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, p.total); return DYGNN_E_WORKSPACE; }
+    hipStream_t s = as_stream(stream);
+    char* ws = static_cast<char*>(workspace);
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    auto I32 = [&](size_t off) { return reinterpret_cast<int32_t*>(ws + off); };
+    const int64_t B = batch;
+    // window lengths -> this call's padded lengths (one host sync: they size every product below)
+    if (int rc = window_lengths_device(d, csr, src, dst, times, B, B, ws, p.wl, s)) return rc;
+    CallDims cd;
+    DYGNN_HIP(hipMemcpyAsync(&cd, ws + p.wl.dims, sizeof(CallDims), hipMemcpyDeviceToHost, s));
+    DYGNN_HIP(hipStreamSynchronize(s));
+    seq_lens_host[0] = cd.S_s; seq_lens_host[1] = cd.S_d;
+    const int Ss = cd.S_s, Sd = cd.S_d, Ts = cd.T_s, T = cd.T, S = Ss + Sd;
+    const int64_t M = B * T;
+    const int D = d.D, C = d.C, H = d.H, hd = d.hd;
+    const Drop dr = make_drop(dropout_p, seed);
+    // co-occurrence LUT of this step's weights
+    hipLaunchKernelGGL(k_lut_fwd, dim3((unsigned)(S + 1)), dim3(64), C * sizeof(float), s, w->cooc_w0, w->cooc_b0, w->cooc_w1, w->cooc_b1, S + 1, C,
+                       F32(p.lut), F32(p.hid));
+    DYGNN_LAUNCH_CHECK();
+    EmbedArgs ea{csr->indptr, csr->nbr, csr->eid, csr->ts, src, dst, times, reinterpret_cast<const int32_t*>(ws + p.wl.hist_len),
+                 reinterpret_cast<const int64_t*>(ws + p.wl.end_pos), node_feat, edge_feat, w->time_w, w->time_b, F32(p.lut), B, Ss, Sd, Ts, T, d.P, d.L,
+                 d.Fn, d.Fe, d.Ft, C, I32(p.ids), I32(p.c0), I32(p.c1), F32(p.dts), F32(p.Pn), F32(p.Pe), F32(p.Pt), F32(p.Pc)};
+    hipLaunchKernelGGL(k_embed_inputs, dim3((unsigned)B), dim3(256), (size_t)5 * S * 4, s, ea);
+    DYGNN_LAUNCH_CHECK();
+    // projections (DyGFormer.py:148-157): X0[:, 50ch : 50ch+50] = P_ch . W_ch^T + b_ch
+    const float* PW[4] = {w->proj_node_w, w->proj_edge_w, w->proj_time_w, w->proj_cooc_w};
+    const float* PB[4] = {w->proj_node_b, w->proj_edge_b, w->proj_time_b, w->proj_cooc_b};
+    const size_t PM[4] = {p.Pn, p.Pe, p.Pt, p.Pc};
+    const int PK[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * C};
+    for (int ch = 0; ch < 4; ++ch)
+        if (int rc = mm(s, F32(PM[ch]), PK[ch], false, PW[ch], PK[ch], true, F32(p.X[0]) + ch * C, D, (int)M, C, PK[ch], PB[ch])) return rc;
+    const float scale = (float)sqrt(1.0 / (double)hd);
+    for (int l = 0; l < d.NL; ++l) {
+        const dygnn_encoder_layer_weights& Lw = w->layers[l];
+        const auto& L = p.layer[l];
+        const float* Xin = F32(p.X[l]);
+        hipLaunchKernelGGL(k_ln_fwd, dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, s, Xin, Lw.norm0_weight, Lw.norm0_bias, M, D, F32(L.xn0), F32(L.m0), F32(L.r0));
+        DYGNN_LAUNCH_CHECK();
+        if (int rc = mm(s, F32(L.xn0), D, false, Lw.in_proj_weight, D, true, F32(L.qkv), 3 * D, (int)M, 3 * D, D, Lw.in_proj_bias)) return rc;
+        // S_bh = scale * Q_bh K_bh^T ; batch z = b*H + h
+        if (int rc = mm(s, F32(L.qkv), 3 * D, false, F32(L.qkv) + D, 3 * D, true, F32(L.S), T, T, T, hd, nullptr, scale, 0.f, (int)(B * H), H,
+                        (int64_t)T * 3 * D, hd, (int64_t)T * 3 * D, hd, (int64_t)H * T * T, (int64_t)T * T)) return rc;
+        hipLaunchKernelGGL(k_softmax_fwd, dim3((unsigned)ceil_div(B * H * T, 4)), dim3(256), 0, s, F32(L.S), B * H * T, T, dr, (uint32_t)(4 * l + 0), F32(L.P), F32(L.Pd));
+        DYGNN_LAUNCH_CHECK();
+        // Oa_bh = Pd_bh V_bh
+        if (int rc = mm(s, F32(L.Pd), T, false, F32(L.qkv) + 2 * D, 3 * D, false, F32(L.oa), D, T, hd, T, nullptr, 1.f, 0.f, (int)(B * H), H,
+                        (int64_t)H * T * T, (int64_t)T * T, (int64_t)T * 3 * D, hd, (int64_t)T * D, hd)) return rc;
+        if (int rc = mm(s, F32(L.oa), D, false, Lw.out_proj_weight, D, true, F32(L.ao), D, (int)M, D, D, Lw.out_proj_bias)) return rc;
+        EW(k_drop_add_fwd, M * D, Xin, F32(L.ao), M * D, dr, (uint32_t)(4 * l + 1), F32(L.x1));                                         // DyGFormer.py:456
+        hipLaunchKernelGGL(k_ln_fwd, dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, s, F32(L.x1), Lw.norm1_weight, Lw.norm1_bias, M, D, F32(L.xn1), F32(L.m1), F32(L.r1));
+        DYGNN_LAUNCH_CHECK();
+        if (int rc = mm(s, F32(L.xn1), D, false, Lw.ffn0_weight, D, true, F32(L.hpre), 4 * D, (int)M, 4 * D, D, Lw.ffn0_bias)) return rc;
+        EW(k_gelu_drop_fwd, M * 4 * D, F32(L.hpre), M * 4 * D, dr, (uint32_t)(4 * l + 2), F32(L.hact));                                 // :458
+        if (int rc = mm(s, F32(L.hact), 4 * D, false, Lw.ffn1_weight, 4 * D, true, F32(L.f2), D, (int)M, D, 4 * D, Lw.ffn1_bias)) return rc;
+        EW(k_drop_add_fwd, M * D, F32(L.x1), F32(L.f2), M * D, dr, (uint32_t)(4 * l + 3), F32(p.X[l + 1]));                             // :460
+    }
+    hipLaunchKernelGGL(k_pool_fwd, dim3((unsigned)B), dim3(256), 0, s, F32(p.X[d.NL]), B, Ts, T, D, F32(p.pooled));
+    DYGNN_LAUNCH_CHECK();
+    if (int rc = mm(s, F32(p.pooled), D, false, w->output_w, D, true, out_src, d.Fn, (int)B, d.Fn, D, w->output_b)) return rc;
+    if (int rc = mm(s, F32(p.pooled) + B * D, D, false, w->output_w, D, true, out_dst, d.Fn, (int)B, d.Fn, D, w->output_b)) return rc;
+    return DYGNN_OK;
+}
+
+extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, const dygnn_dygformer_weights* grads,
+                                        const float* grad_out_src, const float* grad_out_dst, int64_t batch, float dropout_p, uint64_t seed,
+                                        const int32_t* seq_lens_host, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
+    if (int rc = check_config(cfg)) return rc;
+    const Dims d = make_dims(*cfg);
+    if (int rc = supported(d)) return rc;
+    DYGNN_REQUIRE(w && grads && grad_out_src && grad_out_dst && workspace && seq_lens_host && batch > 0, "backward: bad arguments");
+    const Plan p = make_plan(d, batch);
+    if (workspace_bytes < p.total) { set_error("backward: workspace too small (%zu < %zu bytes)", workspace_bytes, p.total); return DYGNN_E_WORKSPACE; }
+    hipStream_t s = as_stream(stream);
+    char* ws = static_cast<char*>(workspace);
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    auto I32 = [&](size_t off) { return reinterpret_cast<int32_t*>(ws + off); };
+    auto G = [](const float* q) { return const_cast<float*>(q); };        // the grads struct reuses the weights layout; its buffers are written
+    const int64_t B = batch;
+    const int Ss = seq_lens_host[0], Sd = seq_lens_host[1], S = Ss + Sd;
+    DYGNN_REQUIRE(Ss > 0 && Sd > 0 && Ss % d.P == 0 && Sd % d.P == 0 && S <= 2 * d.Smax, "backward: bad sequence lengths");
+    const int Ts = Ss / d.P, T = S / d.P;
+    const int64_t M = B * T;
+    const int D = d.D, C = d.C, H = d.H, hd = d.hd, Fn = d.Fn;
+    const Drop dr = make_drop(dropout_p, seed);
+    const float scale = (float)sqrt(1.0 / (double)hd);
+    // output layer: out = pooled W^T + b over both sides
+    if (int rc = mm(s, grad_out_src, Fn, true, F32(p.pooled), D, false, G(grads->output_w), D, Fn, D, (int)B)) return rc;
+    if (int rc = mm(s, grad_out_dst, Fn, true, F32(p.pooled) + B * D, D, false, G(grads->output_w), D, Fn, D, (int)B, nullptr, 1.f, 1.f)) return rc;
+    if (int rc = colsum(s, grad_out_src, Fn, B, Fn, G(grads->output_b))) return rc;
+    if (int rc = colsum(s, grad_out_dst, Fn, B, Fn, G(grads->output_b), true)) return rc;
+    if (int rc = mm(s, grad_out_src, Fn, false, w->output_w, D, false, F32(p.dpool), D, (int)B, D, Fn)) return rc;
+    if (int rc = mm(s, grad_out_dst, Fn, false, w->output_w, D, false, F32(p.dpool) + B * D, D, (int)B, D, Fn)) return rc;
+    float* dX = F32(p.dX);
+    EW(k_pool_bwd, M * D, F32(p.dpool), B, Ts, T, D, dX);
+    for (int l = d.NL - 1; l >= 0; --l) {
+        const dygnn_encoder_layer_weights& Lw = w->layers[l];
+        const dygnn_encoder_layer_weights& Lg = grads->layers[l];
+        const auto& L = p.layer[l];
+        float* dA = F32(p.dA);          // [M][D] scratch
+        float* dBf = F32(p.dB);         // [M][D] scratch
+        float* dH = F32(p.dH);          // [M][4D]
+        float* dQKV = F32(p.dQKV);      // [M][3D]
+        // X_{l+1} = X1 + drop(F2), F2 = Hact W2^T + b2
+        EW(k_drop_bwd, M * D, dX, M * D, dr, (uint32_t)(4 * l + 3), dA);                                                       // dF2
+        if (int rc = mm(s, dA, D, true, F32(L.hact), 4 * D, false, G(Lg.ffn1_weight), 4 * D, D, 4 * D, (int)M)) return rc;     // dW2 [D][4D]
+        if (int rc = colsum(s, dA, D, M, D, G(Lg.ffn1_bias))) return rc;
+        if (int rc = mm(s, dA, D, false, Lw.ffn1_weight, 4 * D, false, dH, 4 * D, (int)M, 4 * D, D)) return rc;                 // dHact
+        EW(k_gelu_drop_bwd, M * 4 * D, dH, F32(L.hpre), M * 4 * D, dr, (uint32_t)(4 * l + 2));                                 // dHpre
+        if (int rc = mm(s, dH, 4 * D, true, F32(L.xn1), D, false, G(Lg.ffn0_weight), D, 4 * D, D, (int)M)) return rc;           // dW1 [4D][D]
+        if (int rc = colsum(s, dH, 4 * D, M, 4 * D, G(Lg.ffn0_bias))) return rc;
+        if (int rc = mm(s, dH, 4 * D, false, Lw.ffn0_weight, D, false, dBf, D, (int)M, D, 4 * D)) return rc;                    // dxn1
+        DYGNN_HIP(hipMemsetAsync(G(Lg.norm1_weight), 0, D * sizeof(float), s));
+        DYGNN_HIP(hipMemsetAsync(G(Lg.norm1_bias), 0, D * sizeof(float), s));
+        hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)ceil_div(M, 64)), dim3(256), 2 * D * sizeof(float), s, dBf, F32(L.x1), F32(L.m1), F32(L.r1), Lw.norm1_weight, M, D,
+                           dX, G(Lg.norm1_weight), G(Lg.norm1_bias));                                                          // dX is now dX1
+        DYGNN_LAUNCH_CHECK();
+        // X1 = Xin + drop(Ao), Ao = Oa Wo^T + bo
+        EW(k_drop_bwd, M * D, dX, M * D, dr, (uint32_t)(4 * l + 1), dA);                                                       // dAo
+        if (int rc = mm(s, dA, D, true, F32(L.oa), D, false, G(Lg.out_proj_weight), D, D, D, (int)M)) return rc;
+        if (int rc = colsum(s, dA, D, M, D, G(Lg.out_proj_bias))) return rc;
+        if (int rc = mm(s, dA, D, false, Lw.out_proj_weight, D, false, dBf, D, (int)M, D, D)) return rc;                        // dOa
+        // attention: Oa_bh = Pd_bh V_bh ; S_bh = scale Q_bh K_bh^T
+        // dV_bh = Pd^T dOa_bh
+        if (int rc = mm(s, F32(L.Pd), T, true, dBf, D, false, dQKV + 2 * D, 3 * D, T, hd, T, nullptr, 1.f, 0.f, (int)(B * H), H, (int64_t)H * T * T, (int64_t)T * T,
+                        (int64_t)T * D, hd, (int64_t)T * 3 * D, hd)) return rc;
+        // dPd_bh = dOa_bh V_bh^T  (into the S buffer)
+        if (int rc = mm(s, dBf, D, false, F32(L.qkv) + 2 * D, 3 * D, true, F32(L.S), T, T, T, hd, nullptr, 1.f, 0.f, (int)(B * H), H, (int64_t)T * D, hd,
+                        (int64_t)T * 3 * D, hd, (int64_t)H * T * T, (int64_t)T * T)) return rc;
+        hipLaunchKernelGGL(k_softmax_bwd, dim3((unsigned)ceil_div(B * H * T, 4)), dim3(256), 0, s, F32(L.S), F32(L.P), B * H * T, T, dr, (uint32_t)(4 * l + 0));
+        DYGNN_LAUNCH_CHECK();
+        // dQ_bh = scale dS K_bh ; dK_bh = scale dS^T Q_bh
+        if (int rc = mm(s, F32(L.S), T, false, F32(L.qkv) + D, 3 * D, false, dQKV, 3 * D, T, hd, T, nullptr, scale, 0.f, (int)(B * H), H, (int64_t)H * T * T,
+                        (int64_t)T * T, (int64_t)T * 3 * D, hd, (int64_t)T * 3 * D, hd)) return rc;
+        if (int rc = mm(s, F32(L.S), T, true, F32(L.qkv), 3 * D, false, dQKV + D, 3 * D, T, hd, T, nullptr, scale, 0.f, (int)(B * H), H, (int64_t)H * T * T,
+                        (int64_t)T * T, (int64_t)T * 3 * D, hd, (int64_t)T * 3 * D, hd)) return rc;
+        if (int rc = mm(s, dQKV, 3 * D, true, F32(L.xn0), D, false, G(Lg.in_proj_weight), D, 3 * D, D, (int)M)) return rc;      // dWin [3D][D]
+        if (int rc = colsum(s, dQKV, 3 * D, M, 3 * D, G(Lg.in_proj_bias))) return rc;
+        if (int rc = mm(s, dQKV, 3 * D, false, Lw.in_proj_weight, D, false, dA, D, (int)M, D, 3 * D)) return rc;                // dxn0
+        DYGNN_HIP(hipMemsetAsync(G(Lg.norm0_weight), 0, D * sizeof(float), s));
+        DYGNN_HIP(hipMemsetAsync(G(Lg.norm0_bias), 0, D * sizeof(float), s));
+        hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)ceil_div(M, 64)), dim3(256), 2 * D * sizeof(float), s, dA, F32(p.X[l]), F32(L.m0), F32(L.r0), Lw.norm0_weight, M, D,
+                           dX, G(Lg.norm0_weight), G(Lg.norm0_bias));                                                          // dX is now dX_l
+        DYGNN_LAUNCH_CHECK();
+    }
+    // projections: X0[:, ch] = P_ch W_ch^T + b_ch
+    const float* PW[4] = {w->proj_node_w, w->proj_edge_w, w->proj_time_w, w->proj_cooc_w};
+    float* GW[4] = {G(grads->proj_node_w), G(grads->proj_edge_w), G(grads->proj_time_w), G(grads->proj_cooc_w)};
+    float* GB[4] = {G(grads->proj_node_b), G(grads->proj_edge_b), G(grads->proj_time_b), G(grads->proj_cooc_b)};
+    const size_t PM[4] = {p.Pn, p.Pe, p.Pt, p.Pc};
+    const int PK[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * C};
+    for (int ch = 0; ch < 4; ++ch) {
+        if (int rc = mm(s, dX + ch * C, D, true, F32(PM[ch]), PK[ch], false, GW[ch], PK[ch], C, PK[ch], (int)M)) return rc;     // dW_ch [C][K]
+        if (int rc = colsum(s, dX + ch * C, D, M, C, GB[ch])) return rc;
+    }
+    // time encoder
+    if (int rc = mm(s, dX + 2 * C, D, false, PW[2], PK[2], false, F32(p.dPt), PK[2], (int)M, PK[2], C)) return rc;
+    DYGNN_HIP(hipMemsetAsync(G(grads->time_w), 0, d.Ft * sizeof(float), s));
+    DYGNN_HIP(hipMemsetAsync(G(grads->time_b), 0, d.Ft * sizeof(float), s));
+    hipLaunchKernelGGL(k_time_bwd, dim3((unsigned)B), dim3(256), 2 * d.Ft * sizeof(float), s, F32(p.dPt), I32(p.ids), F32(p.dts), w->time_w, w->time_b, B, Ss, Sd, Ts, T,
+                       d.P, d.Ft, G(grads->time_w), G(grads->time_b));
+    DYGNN_LAUNCH_CHECK();
+    // co-occurrence encoder
+    if (int rc = mm(s, dX + 3 * C, D, false, PW[3], PK[3], false, F32(p.dPc), PK[3], (int)M, PK[3], C)) return rc;
+    DYGNN_HIP(hipMemsetAsync(F32(p.dlut), 0, (size_t)(S + 1) * C * sizeof(float), s));
+    hipLaunchKernelGGL(k_cooc_bwd, dim3((unsigned)B), dim3(256), 0, s, F32(p.dPc), I32(p.c0), I32(p.c1), B, Ss, Sd, Ts, T, d.P, C, F32(p.dlut));
+    DYGNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_lut_bwd, dim3(1), dim3(256), 0, s, F32(p.dlut), F32(p.hid), w->cooc_w1, S + 1, C, G(grads->cooc_w0), G(grads->cooc_b0), G(grads->cooc_w1),
+                       G(grads->cooc_b1));
+    DYGNN_LAUNCH_CHECK();
+    return DYGNN_OK;
+}

@@ -6,9 +6,11 @@ projection, both encoder layers, pooling, output layer) runs inside libdygnn_hip
 round trip: the reference's numpy hop (sampling/padding/counting on the host CPU,
 models/DyGFormer.py:78-106) disappears and ids never leave the GPU.
 
-Round-1 scope: inference forward (eval mode / no_grad — exactly what
-evaluate_models_utils.py:41-45 sets up).  The training-mode forward (dropout) and the backward
-pass are SURVEY.md §8f-1 and raise NotImplementedError instead of silently detaching.
+Inference (eval mode, or no_grad) runs the fused kernel.  In training mode — or whenever autograd is
+recording in eval mode — the call goes through `_TrainFunction`: the training forward of
+dygformer_train.hip (dropout from a counter-based generator, activations kept in a per-call
+workspace) and its hand-written backward pass, so `loss.backward()` / `optimizer.step()` of
+train_link_prediction.py:229-257 work unchanged.
 """
 from __future__ import annotations
 
@@ -47,6 +49,51 @@ class TransformerEncoder(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.linear_layers = nn.ModuleList([nn.Linear(attention_dim, 4 * attention_dim), nn.Linear(4 * attention_dim, attention_dim)])
         self.norm_layers = nn.ModuleList([nn.LayerNorm(attention_dim), nn.LayerNorm(attention_dim)])
+
+
+class _TrainFunction(torch.autograd.Function):
+    """compute_src_dst_node_temporal_embeddings with gradients: forward = dygnn_dygformer_train_forward, backward =
+    dygnn_dygformer_backward.  The parameters are passed as inputs only so that autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, model, src, dst, tms, dropout_p, seed, *params):
+        dev = src.device
+        B = src.numel()
+        lib, cfg = model._lib, model._cfg
+        weights = model._weights_struct()
+        nbytes = lib.dygnn_dygformer_train_workspace_bytes(C.byref(cfg), B)
+        if nbytes == 0:
+            _capi.check(-3)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)          # lives until this call's backward
+        out_src = torch.empty((B, model.node_feat_dim), dtype=torch.float32, device=dev)
+        out_dst = torch.empty_like(out_src)
+        seq = (C.c_int32 * 2)()
+        csr = model.neighbor_sampler.csr.on_device(dev)
+        rc = lib.dygnn_dygformer_train_forward(C.byref(cfg), C.byref(weights), csr, model.node_raw_features.data_ptr(),
+                                               model.edge_raw_features.data_ptr(), src.data_ptr(), dst.data_ptr(), tms.data_ptr(), B,
+                                               float(dropout_p), int(seed), out_src.data_ptr(), out_dst.data_ptr(), ws.data_ptr(), nbytes,
+                                               C.cast(seq, C.c_void_p), _capi.current_stream_ptr())
+        _capi.check(rc)
+        ctx.model, ctx.ws, ctx.seq, ctx.B, ctx.dropout_p, ctx.seed = model, ws, seq, B, float(dropout_p), int(seed)
+        ctx.param_shapes = [p.shape for p in params]
+        return out_src, out_dst
+
+    @staticmethod
+    def backward(ctx, g_src, g_dst):
+        model = ctx.model
+        dev = ctx.ws.device
+        g_src = (g_src if g_src is not None else torch.zeros((ctx.B, model.node_feat_dim), device=dev)).contiguous().float()
+        g_dst = (g_dst if g_dst is not None else torch.zeros((ctx.B, model.node_feat_dim), device=dev)).contiguous().float()
+        params = list(model.parameters())
+        grads = [torch.zeros_like(p) for p in params]
+        gstruct = model._weights_struct(dict(zip((n for n, _ in model.named_parameters()), grads)))
+        weights = model._weights_struct()
+        rc = model._lib.dygnn_dygformer_backward(C.byref(model._cfg), C.byref(weights), C.byref(gstruct), g_src.data_ptr(), g_dst.data_ptr(), ctx.B,
+                                                 ctx.dropout_p, ctx.seed, C.cast(ctx.seq, C.c_void_p), ctx.ws.data_ptr(), ctx.ws.numel(),
+                                                 _capi.current_stream_ptr())
+        _capi.check(rc)
+        ctx.ws = None
+        return (None, None, None, None, None, None, *grads)
 
 
 class DyGFormer(nn.Module):
@@ -108,9 +155,6 @@ class DyGFormer(nn.Module):
                                                  ) -> Tuple[torch.Tensor, torch.Tensor]:
         """models/DyGFormer.py:68-194.  ndarray (or already-resident device tensor) [B] int64, [B] int64,
         [B] float64 -> two float32 tensors [B, node_feat_dim] on the model's device."""
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training-mode forward / backward through the HIP path is not built yet "
-                                      "(SURVEY.md §8f-1); call under model.eval() + torch.no_grad()")
         dev = self._device()
         src = self._to_dev(src_node_ids, torch.int64, dev)
         dst = self._to_dev(dst_node_ids, torch.int64, dev)
@@ -118,6 +162,16 @@ class DyGFormer(nn.Module):
         B = src.numel()
         if not (dst.numel() == B and tms.numel() == B):
             raise AssertionError("src_node_ids, dst_node_ids and node_interact_times must have the same length")
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if (self.training or needs_grad) and B > 0 and _taps is None:
+            for p in self.parameters():
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise _capi.DygnnError("parameters must be contiguous float32")
+            p_drop = float(self.dropout) if self.training else 0.0
+            seed = getattr(self, "_fixed_dropout_seed", None)             # tests pin the masks; normally torch.manual_seed governs them
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            return _TrainFunction.apply(self, src, dst, tms, p_drop, seed, *self.parameters())
         out_src = torch.empty((B, self.node_feat_dim), dtype=torch.float32, device=dev)
         out_dst = torch.empty_like(out_src)
         if B == 0:
@@ -171,9 +225,15 @@ class DyGFormer(nn.Module):
             return x.to(device=dev, dtype=dtype).contiguous()
         return torch.from_numpy(np.ascontiguousarray(x, dtype={torch.int64: np.int64, torch.float64: np.float64}[dtype])).to(dev, non_blocking=True)
 
-    def _weights_struct(self) -> "_capi.DygformerWeights":
+    def _weights_struct(self, replace: Optional[dict] = None) -> "_capi.DygformerWeights":
+        """ctypes view of the parameters; `replace` maps parameter names to other tensors of the same shapes (the gradient
+        buffers of the backward pass)."""
         w = _capi.DygformerWeights()
-        p = lambda t: t.data_ptr()
+        if replace is None:
+            p = lambda t: t.data_ptr()
+        else:
+            by_id = {id(t): replace[n] for n, t in self.named_parameters()}
+            p = lambda t: by_id[id(t)].data_ptr()
         enc = self.neighbor_co_occurrence_encoder.neighbor_co_occurrence_encode_layer
         w.time_w, w.time_b = p(self.time_encoder.w.weight), p(self.time_encoder.w.bias)
         w.cooc_w0, w.cooc_b0, w.cooc_w1, w.cooc_b1 = p(enc[0].weight), p(enc[0].bias), p(enc[2].weight), p(enc[2].bias)

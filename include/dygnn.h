@@ -241,6 +241,27 @@ int dygnn_tgn_forward(const dygnn_tgat_config* cfg_host, const dygnn_tgat_weight
                       int64_t batch, int32_t edges_are_positive, float* out_src, float* out_dst,
                       void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
 
+/* ---- training: train_link_prediction.py:229-257 on the HIP path ------------------------------------
+ * dygnn_dygformer_train_forward = models/DyGFormer.py:68-194 in TRAIN mode: dropout (probability dropout_p) on the attention
+ * probabilities, the attention output and the FFN (models/DyGFormer.py:429-431, :456-460), masks drawn from a counter-based
+ * generator keyed by `seed` (statistically, not bitwise, the reference's torch masks; dropout_p = 0 reproduces the eval
+ * forward).  It keeps every activation the backward pass needs in `workspace` (size from
+ * dygnn_dygformer_train_workspace_bytes; must stay untouched until dygnn_dygformer_backward of the same call returns) and
+ * writes this call's padded lengths (S_src, S_dst) to seq_lens_host[2] (one host synchronisation).
+ * dygnn_dygformer_backward: `grads` has the layout of dygnn_dygformer_weights but its pointers are WRITABLE device buffers
+ * of the parameter shapes; every one is overwritten with d(sum(out_src*grad_out_src) + sum(out_dst*grad_out_dst))/dparam.
+ * The feature tables receive no gradient (constants in the reference, models/DyGFormer.py:28-29). */
+size_t dygnn_dygformer_train_workspace_bytes(const dygnn_dygformer_config* cfg_host, int64_t batch);
+int dygnn_dygformer_train_forward(const dygnn_dygformer_config* cfg_host, const dygnn_dygformer_weights* w_host,
+                                  const dygnn_csr* csr_host, const float* node_feat, const float* edge_feat,
+                                  const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
+                                  float dropout_p, uint64_t seed, float* out_src, float* out_dst,
+                                  void* workspace, size_t workspace_bytes, int32_t* seq_lens_host, dygnn_stream_t stream);
+int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg_host, const dygnn_dygformer_weights* w_host,
+                             const dygnn_dygformer_weights* grads_host, const float* grad_out_src, const float* grad_out_dst,
+                             int64_t batch, float dropout_p, uint64_t seed, const int32_t* seq_lens_host,
+                             void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
+
 /* Caller-side link predictor, fused: sigmoid(MergeLayer(a,b)) with
  * MergeLayer = fc2(relu(fc1(cat(a,b)))) (models/modules.py:57-68; evaluate_models_utils.py:140-141).
  * a,b [n,dim]; fc1 [hidden, 2*dim]; fc2 [1,hidden]; out [n]. */

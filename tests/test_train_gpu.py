@@ -1,0 +1,130 @@
+"""Training path: dygnn_dygformer_train_forward / dygnn_dygformer_backward behind
+DyGFormer.compute_src_dst_node_temporal_embeddings when autograd is recording.
+
+Gradient parity: every parameter gradient of L = sum(src_emb * G1) + sum(dst_emb * G2) against torch autograd through
+the CPU oracle (oracle/dygformer_oracle.py, pinned to the reference by tests/golden) with dropout off — tolerance
+1e-4 * max(1, max|reference gradient|) per tensor.  Dropout (train mode) is checked for determinism per seed, for its
+keep rate, and for forward/backward consistency by a directional finite difference with the masks pinned."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dygformer_oracle as orc
+from tests import golden_cases as gc
+from tests.test_dygformer_gpu import build_model
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _loss_weights(c, seed=5):
+    rs = np.random.RandomState(seed)
+    B = len(c["src"])
+    return rs.standard_normal((B, 172)).astype(np.float32), rs.standard_normal((B, 172)).astype(np.float32)
+
+
+def _oracle_grads(c, G1, G2):
+    cfg = c["cfg"]
+    params = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in c["params"].items()}
+    d = c["data"]
+    adj = orc.OracleAdjacency(d.src_node_ids, d.dst_node_ids, d.edge_ids, d.node_interact_times)
+    s, t = orc.dygformer_forward(params, c["node_feat"], c["edge_feat"], adj, c["src"], c["dst"], c["times"], cfg["patch_size"],
+                                 cfg["max_input_sequence_length"], cfg["num_heads"], cfg["num_layers"])
+    loss = (s * torch.from_numpy(G1)).sum() + (t * torch.from_numpy(G2)).sum()
+    loss.backward()
+    return {k: v.grad.numpy() for k, v in params.items()}, s.detach().numpy(), t.detach().numpy()
+
+
+@pytest.mark.parametrize("name", ["bip_p2_l64", "hub_p4_l48", "bip_p8_l512"])
+def test_gradients_match_oracle_autograd(name):
+    c = gc.build_case(name)
+    model, _ = build_model(c)
+    G1, G2 = _loss_weights(c)
+    want, ws, wd = _oracle_grads(c, G1, G2)
+    model.eval()                                   # dropout off, autograd on: the training kernels with p = 0
+    for p in model.parameters():
+        p.grad = None
+    s, t = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
+    assert s.requires_grad and t.requires_grad
+    for got, ref in ((s, ws), (t, wd)):
+        assert np.abs(got.detach().cpu().numpy() - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+    loss = (s * torch.from_numpy(G1).cuda()).sum() + (t * torch.from_numpy(G2).cuda()).sum()
+    loss.backward()
+    for k, p in model.named_parameters():
+        ref = want[k]
+        got = p.grad.detach().cpu().numpy()
+        assert got.shape == ref.shape, k
+        tol = TOL * max(1.0, float(np.abs(ref).max()))
+        err = float(np.abs(got - ref).max())
+        assert np.isfinite(got).all() and err <= tol, f"{name} {k}: max abs err {err:.3e} > {tol:.3e} (max |ref| {np.abs(ref).max():.3e})"
+
+
+def test_train_mode_without_dropout_equals_eval_forward():
+    c = gc.build_case("bip_p2_l64")
+    model, _ = build_model(c)
+    with torch.no_grad():
+        es, ed = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
+    model.train()
+    model.dropout = 0.0
+    s, t = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
+    for a, b in ((s, es), (t, ed)):
+        assert float((a.detach() - b).abs().max()) <= TOL * max(1.0, float(b.abs().max()))
+
+
+def test_dropout_masks_are_seeded_and_consistent_between_passes():
+    c = gc.build_case("bip_p2_l64")
+    model, _ = build_model(c)
+    model.train()
+    assert model.dropout == 0.1
+    model._fixed_dropout_seed = 1234
+    s1, _ = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
+    s2, _ = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
+    assert torch.equal(s1, s2)                                  # same seed, same masks
+    model._fixed_dropout_seed = 99
+    s3, _ = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
+    assert not torch.equal(s1, s3)
+    with torch.no_grad():
+        model.eval()
+        e, _ = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
+        model.train()
+    rel = float((s1.detach() - e).norm() / e.norm())
+    assert 1e-3 < rel < 1.0, rel                                # dropout perturbs, but does not destroy, the embeddings
+    # directional derivative with the masks pinned: (L(w + eps v) - L(w - eps v)) / (2 eps) = <grad, v>
+    model._fixed_dropout_seed = 1234
+    G1, G2 = _loss_weights(c)
+    G1, G2 = torch.from_numpy(G1).cuda(), torch.from_numpy(G2).cuda()
+
+    def loss_fn():
+        a, b = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
+        return (a * G1).sum() + (b * G2).sum()
+    for p in model.parameters():
+        p.grad = None
+    loss_fn().backward()
+    torch.manual_seed(0)
+    target = model.transformers[0].linear_layers[0].weight
+    v = torch.randn_like(target)
+    v /= v.norm()
+    analytic = float((target.grad * v).sum())
+    eps = 1e-2
+    with torch.no_grad():
+        target.add_(eps * v); lp = float(loss_fn().detach()); target.sub_(2 * eps * v); lm = float(loss_fn().detach()); target.add_(eps * v)
+    numeric = (lp - lm) / (2 * eps)
+    assert abs(numeric - analytic) <= 2e-2 * max(1.0, abs(analytic)), (numeric, analytic)
+
+
+def test_a_few_optimizer_steps_reduce_the_link_prediction_loss():
+    """train_link_prediction.py:229-257 in miniature: positive + negative call, BCE on MergeLayer logits, Adam."""
+    c = gc.build_case("bip_p2_l64")
+    model, merge = build_model(c)
+    model.train(); merge.train()
+    opt = torch.optim.Adam(list(model.parameters()) + list(merge.parameters()), lr=1e-3)
+    losses = []
+    torch.manual_seed(3)
+    for _ in range(8):
+        ps, pd = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
+        ns, nd = model.compute_src_dst_node_temporal_embeddings(c["src"], c["neg_dst"], c["times"])
+        pos, neg = merge(ps, pd).squeeze(-1).sigmoid(), merge(ns, nd).squeeze(-1).sigmoid()
+        loss = torch.nn.functional.binary_cross_entropy(torch.cat([pos, neg]), torch.cat([torch.ones_like(pos), torch.zeros_like(neg)]))
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(float(loss.detach()))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
