@@ -85,32 +85,142 @@ __global__ __launch_bounds__(256) void k_mm(const MM p) {
     }
 }
 
+// The large products: 128 x (32*WN) tile per workgroup, 4 waves as 2 x 2, each wave 4 x WN accumulator tiles; operands go
+// through LDS in k-major layout ([16 k][tile + 4]) with float4 global loads when pointers / leading dimensions allow
+// (vecA / vecB), so one k-step of 16 costs a wave 8 or 6 LDS reads per 16 or 8 MFMAs instead of k_mm's 5 per 4.
+template <int WN>
+__global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, const int vecB) {
+    constexpr int BM = 128, BN = 32 * WN;
+    __shared__ float As[16][BM + 4];
+    __shared__ float Bs[16][BN + 4];
+    const int z = blockIdx.z, zb = z / p.H, zh = z % p.H;
+    const float* A = p.A + zb * p.sAb + zh * p.sAh;
+    const float* Bm = p.B + zb * p.sBb + zh * p.sBh;
+    float* C = p.C + zb * p.sCb + zh * p.sCh;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wy = wave >> 1, wx = wave & 1;
+    const int c = lane & 15, g = lane >> 4;
+    f4 acc[4][WN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    auto ldA = [&](int m, int k) -> float {      // op(A)[m][k], zero outside
+        if (m >= p.M || k >= p.K) return 0.f;
+        return p.transA ? A[(size_t)k * p.lda + m] : A[(size_t)m * p.lda + k];
+    };
+    auto ldB = [&](int k, int n) -> float {
+        if (n >= p.N || k >= p.K) return 0.f;
+        return p.transB ? Bm[(size_t)n * p.ldb + k] : Bm[(size_t)k * p.ldb + n];
+    };
+    for (int k0 = 0; k0 < p.K; k0 += 16) {
+        // ---- A tile: BM x 16
+        if (p.transA) {                           // stored [K][M]: m contiguous; thread -> (k, 4 consecutive m)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = (tid >> 5) + 8 * e, m = (tid & 31) * 4;
+                f4 v;
+                if (vecA && m0 + m + 3 < p.M && k0 + k < p.K) v = *reinterpret_cast<const f4*>(A + (size_t)(k0 + k) * p.lda + m0 + m);
+                else v = f4{ldA(m0 + m, k0 + k), ldA(m0 + m + 1, k0 + k), ldA(m0 + m + 2, k0 + k), ldA(m0 + m + 3, k0 + k)};
+                *reinterpret_cast<f4*>(&As[k][m]) = v;
+            }
+        } else {                                  // stored [M][K]: k contiguous; thread -> (m, 4 consecutive k)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int m = (tid >> 2) + 64 * e, k = (tid & 3) * 4;
+                f4 v;
+                if (vecA && m0 + m < p.M && k0 + k + 3 < p.K) v = *reinterpret_cast<const f4*>(A + (size_t)(m0 + m) * p.lda + k0 + k);
+                else v = f4{ldA(m0 + m, k0 + k), ldA(m0 + m, k0 + k + 1), ldA(m0 + m, k0 + k + 2), ldA(m0 + m, k0 + k + 3)};
+                As[k][m] = v.x; As[k + 1][m] = v.y; As[k + 2][m] = v.z; As[k + 3][m] = v.w;
+            }
+        }
+        // ---- B tile: 16 x BN
+        if (!p.transB) {                          // stored [K][N]: n contiguous
+#pragma unroll
+            for (int e = 0; e < BN / 64; ++e) {
+                const int k = (tid / (BN / 4)) + (1024 / BN) * e, n = (tid % (BN / 4)) * 4;
+                f4 v;
+                if (vecB && n0 + n + 3 < p.N && k0 + k < p.K) v = *reinterpret_cast<const f4*>(Bm + (size_t)(k0 + k) * p.ldb + n0 + n);
+                else v = f4{ldB(k0 + k, n0 + n), ldB(k0 + k, n0 + n + 1), ldB(k0 + k, n0 + n + 2), ldB(k0 + k, n0 + n + 3)};
+                *reinterpret_cast<f4*>(&Bs[k][n]) = v;
+            }
+        } else {                                  // stored [N][K]: k contiguous
+#pragma unroll
+            for (int e = 0; e < BN / 64; ++e) {
+                const int n = (tid >> 2) + 64 * e, k = (tid & 3) * 4;
+                f4 v;
+                if (vecB && n0 + n < p.N && k0 + k + 3 < p.K) v = *reinterpret_cast<const f4*>(Bm + (size_t)(n0 + n) * p.ldb + k0 + k);
+                else v = f4{ldB(k0 + k, n0 + n), ldB(k0 + k + 1, n0 + n), ldB(k0 + k + 2, n0 + n), ldB(k0 + k + 3, n0 + n)};
+                Bs[k][n] = v.x; Bs[k + 1][n] = v.y; Bs[k + 2][n] = v.z; Bs[k + 3][n] = v.w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float a[4], b[WN];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[4 * kk + g][64 * wy + 16 * i + c];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b[j] = Bs[4 * kk + g][16 * WN * wx + 16 * j + c];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + 16 * WN * wx + 16 * j + c;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 64 * wy + 16 * i + 4 * g + r;
+                if (m >= p.M) continue;
+                float v = p.alpha * acc[i][j][r] + bv;
+                if (p.beta != 0.f) v += p.beta * C[(size_t)m * p.ldc + n];
+                C[(size_t)m * p.ldc + n] = v;
+            }
+    }
+}
+
 static int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb, bool tB, float* C, int ldc, int M, int N, int K,
               const float* bias = nullptr, float alpha = 1.f, float beta = 0.f, int batch = 1, int H = 1, int64_t sAb = 0, int64_t sAh = 0,
               int64_t sBb = 0, int64_t sBh = 0, int64_t sCb = 0, int64_t sCh = 0) {
     if (M <= 0 || N <= 0 || batch <= 0) return DYGNN_OK;
     MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh};
+    if (M >= 128 && N >= 48) {
+        const int vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && lda % 4 == 0 && sAb % 4 == 0 && sAh % 4 == 0) ? 1 : 0;
+        const int vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && ldb % 4 == 0 && sBb % 4 == 0 && sBh % 4 == 0) ? 1 : 0;
+        if (N > 64) hipLaunchKernelGGL((k_mm_big<4>), dim3((unsigned)ceil_div(M, 128), (unsigned)ceil_div(N, 128), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
+        else hipLaunchKernelGGL((k_mm_big<2>), dim3((unsigned)ceil_div(M, 128), (unsigned)ceil_div(N, 64), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
+        DYGNN_LAUNCH_CHECK();
+        return DYGNN_OK;
+    }
     hipLaunchKernelGGL(k_mm, dim3((unsigned)ceil_div(M, 64), (unsigned)ceil_div(N, 64), (unsigned)batch), dim3(256), 0, s, p);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }
 
-// out[n] (+)= sum_m A[m][n]   (bias gradients); one workgroup per 64 columns
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ A, int lda, int64_t M, int N, float* __restrict__ out, int accumulate) {
+// out[n] += sum_m A[m][n]   (bias gradients): workgroup = 64 columns x a chunk of 256 rows, one atomic per column and workgroup
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ A, int lda, int64_t M, int N, float* __restrict__ out) {
     __shared__ float red[4][64];
     const int n = blockIdx.x * 64 + (threadIdx.x & 63), r0 = threadIdx.x >> 6;
+    const int64_t mlo = (int64_t)blockIdx.y * 256, mhi = mlo + 256 < M ? mlo + 256 : M;
     float s = 0.f;
     if (n < N)
-        for (int64_t m = r0; m < M; m += 4) s += A[m * lda + n];
+        for (int64_t m = mlo + r0; m < mhi; m += 4) s += A[m * lda + n];
     red[r0][threadIdx.x & 63] = s;
     __syncthreads();
-    if (r0 == 0 && n < N) {
-        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        out[n] = accumulate ? out[n] + t : t;
-    }
+    if (r0 == 0 && n < N) atomicAdd(&out[n], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 static int colsum(hipStream_t s, const float* A, int lda, int64_t M, int N, float* out, bool accumulate = false) {
-    hipLaunchKernelGGL(k_colsum, dim3((unsigned)ceil_div(N, 64)), dim3(256), 0, s, A, lda, M, N, out, accumulate ? 1 : 0);
+    if (!accumulate) DYGNN_HIP(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s));
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 256)), dim3(256), 0, s, A, lda, M, N, out);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }

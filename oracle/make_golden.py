@@ -140,6 +140,28 @@ def run_loader_case() -> dict:
     return out
 
 
+def run_grad_case(name: str) -> dict:
+    """parameter gradients of the reference DyGFormer (eval mode: dropout identity, autograd on)"""
+    c = gc.build_case(name)
+    d, cfg = c["data"], c["cfg"]
+    ref_data = RefData(d.src_node_ids, d.dst_node_ids, d.node_interact_times, d.edge_ids, d.labels)
+    sampler = ref_get_neighbor_sampler(ref_data, sample_neighbor_strategy="recent", seed=1)
+    model = RefDyGFormer(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"],
+                         channel_embedding_dim=cfg["channel_embedding_dim"], patch_size=cfg["patch_size"],
+                         num_layers=cfg["num_layers"], num_heads=cfg["num_heads"], dropout=0.1,
+                         max_input_sequence_length=cfg["max_input_sequence_length"], device="cpu")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in c["params"].items()}, strict=True)
+    model.eval()
+    G1, G2 = gc.grad_loss_weights(len(c["src"]))
+    se, de = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
+    loss = (se * torch.from_numpy(G1)).sum() + (de * torch.from_numpy(G2)).sum()
+    loss.backward()
+    out = {"loss": np.array(float(loss.detach()))}
+    for k, p in model.named_parameters():
+        out.update(gc.grad_signature(k, p.grad.numpy()))
+    return out
+
+
 def run_tgat_case(name: str) -> dict:
     c = gc.build_tgat_case(name)
     d, cfg = c["data"], c["tgat_cfg"]
@@ -190,8 +212,13 @@ def run_tgn_case(name: str) -> dict:
 def main():
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(8)
-    names = sys.argv[1:] or (list(gc.CASES) + list(gc.TGAT_CASES) + list(gc.TGN_CASES) + ["sampling_" + n for n in gc.SAMPLING_CASES] + ["loader_toy"])
+    names = sys.argv[1:] or (list(gc.CASES) + list(gc.TGAT_CASES) + list(gc.TGN_CASES) + ["sampling_" + n for n in gc.SAMPLING_CASES] + ["loader_toy"] + ["grads_" + n for n in gc.GRAD_CASES])
     for name in names:
+        if name.startswith("grads_"):
+            path = os.path.join(gc.GOLDEN_DIR, name + ".npz")
+            np.savez_compressed(path, **run_grad_case(name[len("grads_"):]))
+            print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+            continue
         if name == "loader_toy":
             np.savez_compressed(os.path.join(gc.GOLDEN_DIR, name + ".npz"), **run_loader_case())
             print(f"{name}: written")

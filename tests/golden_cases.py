@@ -152,3 +152,31 @@ def write_dataset_files(root: str) -> str:
     np.save(os.path.join(d, f"ml_{r['name']}.npy"), ef[:, :r["edge_feat_cols"]])
     np.save(os.path.join(d, f"ml_{r['name']}_node.npy"), nf)
     return r["name"]
+
+
+# ---- gradients (reference model in eval mode with autograd on): L = sum(src_emb * G1) + sum(dst_emb * G2), G from
+# RandomState(GRAD_SEED).  Small tensors are stored whole; the big matrices as their [0:8, 0:8] corner plus 8 random
+# projections <grad, R_i> (R_i from RandomState(GRAD_SEED + 1 + i), standard normal, the gradient's shape).
+GRAD_CASES = ("bip_p2_l64", "hub_p4_l48")
+GRAD_SEED = 5
+GRAD_FULL_MAX = 4096          # tensors up to this many elements are stored whole
+
+
+def grad_loss_weights(B: int):
+    rs = np.random.RandomState(GRAD_SEED)
+    return rs.standard_normal((B, 172)).astype(np.float32), rs.standard_normal((B, 172)).astype(np.float32)
+
+
+def grad_signature(name: str, g: np.ndarray) -> dict:
+    out = {}
+    if g.size <= GRAD_FULL_MAX:
+        out[f"{name}|full"] = g.astype(np.float32)
+        return out
+    out[f"{name}|corner"] = g[:8, :8].astype(np.float32)
+    proj = []
+    for i in range(8):
+        r = np.random.RandomState(GRAD_SEED + 1 + i).standard_normal(g.shape)
+        proj.append(float((g.astype(np.float64) * r).sum()))
+    out[f"{name}|proj"] = np.array(proj, dtype=np.float64)
+    out[f"{name}|absmax"] = np.array(float(np.abs(g).max()))
+    return out
