@@ -30,34 +30,36 @@ struct MM {
     int M, N, K, lda, ldb, ldc, transA, transB;
     float alpha, beta;
     int H; int64_t sAb, sAh, sBb, sBh, sCb, sCh;
+    int ksplit, kchunk;     // split-K: blockIdx.z = batch * ksplit + part; part sums k in [part*kchunk, +kchunk) and adds atomically
 };
 
 __global__ __launch_bounds__(256) void k_mm(const MM p) {
-    __shared__ float As[16][64 + 4];
-    __shared__ float Bs[16][64 + 4];
-    const int z = blockIdx.z, zb = z / p.H, zh = z % p.H;
+    __shared__ float As[16][64 + 16];      // row stride 80 = 16 mod 64 banks: the four k-rows a wave reads at once do not collide
+    __shared__ float Bs[16][64 + 16];
+    const int z = blockIdx.z / p.ksplit, ks = blockIdx.z % p.ksplit, zb = z / p.H, zh = z % p.H;
     const float* A = p.A + zb * p.sAb + zh * p.sAh;
     const float* Bm = p.B + zb * p.sBb + zh * p.sBh;
     float* C = p.C + zb * p.sCb + zh * p.sCh;
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int kbeg = ks * p.kchunk, kend = kbeg + p.kchunk < p.K ? kbeg + p.kchunk : p.K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     f4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < p.K; k0 += 16) {
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = tid + 256 * e;
             int m, k;
             if (p.transA) { m = idx & 63; k = idx >> 6; } else { m = idx >> 4; k = idx & 15; }
             float v = 0.f;
-            if (m0 + m < p.M && k0 + k < p.K) v = p.transA ? A[(size_t)(k0 + k) * p.lda + m0 + m] : A[(size_t)(m0 + m) * p.lda + k0 + k];
+            if (m0 + m < p.M && k0 + k < kend) v = p.transA ? A[(size_t)(k0 + k) * p.lda + m0 + m] : A[(size_t)(m0 + m) * p.lda + k0 + k];
             As[k][m] = v;
             int n, kb;
             if (p.transB) { n = idx >> 4; kb = idx & 15; } else { n = idx & 63; kb = idx >> 6; }
             float w = 0.f;
-            if (n0 + n < p.N && k0 + kb < p.K) w = p.transB ? Bm[(size_t)(n0 + n) * p.ldb + k0 + kb] : Bm[(size_t)(k0 + kb) * p.ldb + n0 + n];
+            if (n0 + n < p.N && k0 + kb < kend) w = p.transB ? Bm[(size_t)(n0 + n) * p.ldb + k0 + kb] : Bm[(size_t)(k0 + kb) * p.ldb + n0 + n];
             Bs[kb][n] = w;
         }
         __syncthreads();
@@ -73,12 +75,13 @@ __global__ __launch_bounds__(256) void k_mm(const MM p) {
     for (int nt = 0; nt < 4; ++nt) {
         const int n = n0 + 16 * nt + c;
         if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+        const float bv = (p.bias && ks == 0) ? p.bias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + 16 * wave + 4 * g + r;
             if (m >= p.M) continue;
             float v = p.alpha * acc[nt][r] + bv;
+            if (p.ksplit > 1) { atomicAdd(&C[(size_t)m * p.ldc + n], v); continue; }
             if (p.beta != 0.f) v += p.beta * C[(size_t)m * p.ldc + n];
             C[(size_t)m * p.ldc + n] = v;
         }
@@ -91,13 +94,14 @@ __global__ __launch_bounds__(256) void k_mm(const MM p) {
 template <int WN>
 __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, const int vecB) {
     constexpr int BM = 128, BN = 32 * WN;
-    __shared__ float As[16][BM + 4];
-    __shared__ float Bs[16][BN + 4];
-    const int z = blockIdx.z, zb = z / p.H, zh = z % p.H;
+    __shared__ float As[16][BM + 16];
+    __shared__ float Bs[16][BN + 16];
+    const int z = blockIdx.z / p.ksplit, ks = blockIdx.z % p.ksplit, zb = z / p.H, zh = z % p.H;
     const float* A = p.A + zb * p.sAb + zh * p.sAh;
     const float* Bm = p.B + zb * p.sBb + zh * p.sBh;
     float* C = p.C + zb * p.sCb + zh * p.sCh;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kbeg = ks * p.kchunk, kend = kbeg + p.kchunk < p.K ? kbeg + p.kchunk : p.K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave >> 1, wx = wave & 1;
     const int c = lane & 15, g = lane >> 4;
@@ -107,21 +111,21 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     auto ldA = [&](int m, int k) -> float {      // op(A)[m][k], zero outside
-        if (m >= p.M || k >= p.K) return 0.f;
+        if (m >= p.M || k >= kend) return 0.f;
         return p.transA ? A[(size_t)k * p.lda + m] : A[(size_t)m * p.lda + k];
     };
     auto ldB = [&](int k, int n) -> float {
-        if (n >= p.N || k >= p.K) return 0.f;
+        if (n >= p.N || k >= kend) return 0.f;
         return p.transB ? Bm[(size_t)n * p.ldb + k] : Bm[(size_t)k * p.ldb + n];
     };
-    for (int k0 = 0; k0 < p.K; k0 += 16) {
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
         // ---- A tile: BM x 16
         if (p.transA) {                           // stored [K][M]: m contiguous; thread -> (k, 4 consecutive m)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int k = (tid >> 5) + 8 * e, m = (tid & 31) * 4;
                 f4 v;
-                if (vecA && m0 + m + 3 < p.M && k0 + k < p.K) v = *reinterpret_cast<const f4*>(A + (size_t)(k0 + k) * p.lda + m0 + m);
+                if (vecA && m0 + m + 3 < p.M && k0 + k < kend) v = *reinterpret_cast<const f4*>(A + (size_t)(k0 + k) * p.lda + m0 + m);
                 else v = f4{ldA(m0 + m, k0 + k), ldA(m0 + m + 1, k0 + k), ldA(m0 + m + 2, k0 + k), ldA(m0 + m + 3, k0 + k)};
                 *reinterpret_cast<f4*>(&As[k][m]) = v;
             }
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
             for (int e = 0; e < 2; ++e) {
                 const int m = (tid >> 2) + 64 * e, k = (tid & 3) * 4;
                 f4 v;
-                if (vecA && m0 + m < p.M && k0 + k + 3 < p.K) v = *reinterpret_cast<const f4*>(A + (size_t)(m0 + m) * p.lda + k0 + k);
+                if (vecA && m0 + m < p.M && k0 + k + 3 < kend) v = *reinterpret_cast<const f4*>(A + (size_t)(m0 + m) * p.lda + k0 + k);
                 else v = f4{ldA(m0 + m, k0 + k), ldA(m0 + m, k0 + k + 1), ldA(m0 + m, k0 + k + 2), ldA(m0 + m, k0 + k + 3)};
                 As[k][m] = v.x; As[k + 1][m] = v.y; As[k + 2][m] = v.z; As[k + 3][m] = v.w;
             }
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
             for (int e = 0; e < BN / 64; ++e) {
                 const int k = (tid / (BN / 4)) + (1024 / BN) * e, n = (tid % (BN / 4)) * 4;
                 f4 v;
-                if (vecB && n0 + n + 3 < p.N && k0 + k < p.K) v = *reinterpret_cast<const f4*>(Bm + (size_t)(k0 + k) * p.ldb + n0 + n);
+                if (vecB && n0 + n + 3 < p.N && k0 + k < kend) v = *reinterpret_cast<const f4*>(Bm + (size_t)(k0 + k) * p.ldb + n0 + n);
                 else v = f4{ldB(k0 + k, n0 + n), ldB(k0 + k, n0 + n + 1), ldB(k0 + k, n0 + n + 2), ldB(k0 + k, n0 + n + 3)};
                 *reinterpret_cast<f4*>(&Bs[k][n]) = v;
             }
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
             for (int e = 0; e < BN / 64; ++e) {
                 const int n = (tid >> 2) + 64 * e, k = (tid & 3) * 4;
                 f4 v;
-                if (vecB && n0 + n < p.N && k0 + k + 3 < p.K) v = *reinterpret_cast<const f4*>(Bm + (size_t)(n0 + n) * p.ldb + k0 + k);
+                if (vecB && n0 + n < p.N && k0 + k + 3 < kend) v = *reinterpret_cast<const f4*>(Bm + (size_t)(n0 + n) * p.ldb + k0 + k);
                 else v = f4{ldB(k0 + k, n0 + n), ldB(k0 + k + 1, n0 + n), ldB(k0 + k + 2, n0 + n), ldB(k0 + k + 3, n0 + n)};
                 Bs[k][n] = v.x; Bs[k + 1][n] = v.y; Bs[k + 2][n] = v.z; Bs[k + 3][n] = v.w;
             }
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
     for (int j = 0; j < WN; ++j) {
         const int n = n0 + 16 * WN * wx + 16 * j + c;
         if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+        const float bv = (p.bias && ks == 0) ? p.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
                 const int m = m0 + 64 * wy + 16 * i + 4 * g + r;
                 if (m >= p.M) continue;
                 float v = p.alpha * acc[i][j][r] + bv;
+                if (p.ksplit > 1) { atomicAdd(&C[(size_t)m * p.ldc + n], v); continue; }
                 if (p.beta != 0.f) v += p.beta * C[(size_t)m * p.ldc + n];
                 C[(size_t)m * p.ldc + n] = v;
             }
@@ -192,7 +197,15 @@ static int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, i
               const float* bias = nullptr, float alpha = 1.f, float beta = 0.f, int batch = 1, int H = 1, int64_t sAb = 0, int64_t sAh = 0,
               int64_t sBb = 0, int64_t sBh = 0, int64_t sCb = 0, int64_t sCh = 0) {
     if (M <= 0 || N <= 0 || batch <= 0) return DYGNN_OK;
-    MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh};
+    MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh, 1, K};
+    // weight gradients: small output, K = all rows of the call -> split K over workgroups, partial sums meet by atomicAdd
+    if (batch == 1 && K >= 2048) {
+        p.kchunk = 256;
+        p.ksplit = (K + p.kchunk - 1) / p.kchunk;
+        if (beta == 0.f) DYGNN_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s));
+        p.beta = 0.f;
+    }
+    batch *= p.ksplit;
     if (M >= 128 && N >= 48) {
         const int vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && lda % 4 == 0 && sAb % 4 == 0 && sAh % 4 == 0) ? 1 : 0;
         const int vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && ldb % 4 == 0 && sBb % 4 == 0 && sBh % 4 == 0) ? 1 : 0;
