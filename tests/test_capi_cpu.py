@@ -115,9 +115,9 @@ def test_module_state_dict_matches_reference_keys(lib):
         m.eval()
         with torch.no_grad():
             m.compute_src_dst_node_temporal_embeddings(data.src_node_ids[:2], data.dst_node_ids[:2], data.node_interact_times[:2])
-    # training-mode forward is not silently detached
+    # the training path is HIP too: a CPU-resident model refuses it the same way
     m.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(_capi.DygnnError):
         m.compute_src_dst_node_temporal_embeddings(data.src_node_ids[:2], data.dst_node_ids[:2], data.node_interact_times[:2])
 
 
