@@ -466,44 +466,67 @@ __global__ __launch_bounds__(256) void k_time_bwd(const float* __restrict__ dPt,
     __syncthreads();
     for (int k = threadIdx.x; k < Ft; k += 256) { atomicAdd(&dw[k], part[k]); atomicAdd(&db[k], part[Ft + k]); }
 }
-// dlut[count][j] += dPc over both count channels (feature = lut[c0] + lut[c1], DyGFormer.py:409-411)
+// dlut[count][j] += dPc over both count channels (feature = lut[c0] + lut[c1], DyGFormer.py:409-411).
+// One workgroup handles kPairsPerWg pairs.  Thread (grp, j) owns column j of its own LDS copy [grp][count < 16][C] and walks
+// every 5th (token, position) of the pair, so the hot counts (0, 1, 2, ...) are summed without atomics; the five copies are
+// then folded into the global table with one atomic per (count, column) and workgroup.  Counts >= 16 go straight to global.
+constexpr int kCoocRows = 16, kCoocGroups = 5, kPairsPerWg = 8;
 __global__ __launch_bounds__(256) void k_cooc_bwd(const float* __restrict__ dPc, const int32_t* __restrict__ c0, const int32_t* __restrict__ c1, int64_t B,
                                                     int Ss, int Sd, int Ts, int T, int P, int C, float* __restrict__ dlut) {
+    extern __shared__ float acc[];             // [5][16][C]
     const int S = Ss + Sd, Kc = P * C;
-    const int64_t b = blockIdx.x;
-    for (int idx = threadIdx.x; idx < T * Kc; idx += 256) {
-        const int tok = idx / Kc, k = idx - tok * Kc, j = k % C;
-        const int pp = (tok < Ts ? tok * P : Ss + (tok - Ts) * P) + k / C;
-        const float gv = dPc[(b * T + tok) * Kc + k];
-        atomicAdd(&dlut[(size_t)c0[b * S + pp] * C + j], gv);
-        atomicAdd(&dlut[(size_t)c1[b * S + pp] * C + j], gv);
+    for (int i = threadIdx.x; i < kCoocGroups * kCoocRows * C; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    const int grp = threadIdx.x / C, j = threadIdx.x % C;
+    if (grp < kCoocGroups) {
+        float* mine = acc + (size_t)grp * kCoocRows * C;
+        for (int64_t b = (int64_t)blockIdx.x * kPairsPerWg; b < B && b < (int64_t)(blockIdx.x + 1) * kPairsPerWg; ++b) {
+            for (int q = grp; q < T * P; q += kCoocGroups) {          // q = token * P + position inside the patch
+                const int tok = q / P, pin = q - tok * P;
+                const int pp = (tok < Ts ? tok * P : Ss + (tok - Ts) * P) + pin;
+                const float gv = dPc[(b * T + tok) * Kc + pin * C + j];
+                const int32_t a0 = c0[b * S + pp], a1 = c1[b * S + pp];
+                if (a0 < kCoocRows) mine[a0 * C + j] += gv; else atomicAdd(&dlut[(size_t)a0 * C + j], gv);
+                if (a1 < kCoocRows) mine[a1 * C + j] += gv; else atomicAdd(&dlut[(size_t)a1 * C + j], gv);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kCoocRows * C; i += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int gq = 0; gq < kCoocGroups; ++gq) t += acc[(size_t)gq * kCoocRows * C + i];
+        if (t != 0.f) atomicAdd(&dlut[i], t);
     }
 }
-// gradients of the co-occurrence MLP from dlut (one workgroup; rows <= a few hundred, C = 50)
-__global__ __launch_bounds__(256) void k_lut_bwd(const float* __restrict__ dlut, const float* __restrict__ hid, const float* __restrict__ w1, int rows, int C,
+// gradients of the co-occurrence MLP from dlut: dh[c][k] = (hid[c][k] > 0) sum_j w1[j][k] dlut[c][j]  (one workgroup per count)
+__global__ void k_lut_bwd_hidden(const float* __restrict__ dlut, const float* __restrict__ hid, const float* __restrict__ w1, int C, float* __restrict__ dh) {
+    const int c = blockIdx.x;
+    for (int k = threadIdx.x; k < C; k += blockDim.x) {
+        float v = 0.f;
+        if (hid[c * C + k] > 0.f)
+            for (int j = 0; j < C; ++j) v = fmaf(w1[j * C + k], dlut[c * C + j], v);
+        dh[c * C + k] = v;
+    }
+}
+// dw1[j][k] = sum_c dlut[c][j] hid[c][k] ; db1[j] = sum_c dlut[c][j] ; dw0[k] = sum_c dh[c][k] * c ; db0[k] = sum_c dh[c][k]
+__global__ __launch_bounds__(256) void k_lut_bwd(const float* __restrict__ dlut, const float* __restrict__ hid, const float* __restrict__ dh, int rows, int C,
                                                    float* __restrict__ dw0, float* __restrict__ db0, float* __restrict__ dw1, float* __restrict__ db1) {
-    // dw1[j][k] = sum_c dlut[c][j] hid[c][k] ; db1[j] = sum_c dlut[c][j] ; dh[c][k] = (hid > 0) sum_j w1[j][k] dlut[c][j]
-    // dw0[k] = sum_c dh[c][k] * c ; db0[k] = sum_c dh[c][k]
-    for (int idx = threadIdx.x; idx < C * C; idx += 256) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < C * C) {
         const int j = idx / C, k = idx % C;
         float acc = 0.f;
         for (int c = 0; c < rows; ++c) acc = fmaf(dlut[c * C + j], hid[c * C + k], acc);
         dw1[idx] = acc;
-    }
-    for (int j = threadIdx.x; j < C; j += 256) {
+    } else if (idx < C * C + C) {
+        const int j = idx - C * C;
         float acc = 0.f;
         for (int c = 0; c < rows; ++c) acc += dlut[c * C + j];
         db1[j] = acc;
-    }
-    for (int k = threadIdx.x; k < C; k += 256) {
+    } else if (idx < C * C + 2 * C) {
+        const int k = idx - C * C - C;
         float aw = 0.f, ab = 0.f;
-        for (int c = 0; c < rows; ++c) {
-            if (hid[c * C + k] > 0.f) {
-                float dh = 0.f;
-                for (int j = 0; j < C; ++j) dh = fmaf(w1[j * C + k], dlut[c * C + j], dh);
-                aw = fmaf(dh, (float)c, aw); ab += dh;
-            }
-        }
+        for (int c = 0; c < rows; ++c) { const float v = dh[c * C + k]; aw = fmaf(v, (float)c, aw); ab += v; }
         dw0[k] = aw; db0[k] = ab;
     }
 }
@@ -562,6 +585,7 @@ static Plan make_plan(const Dims& d, int64_t B) {
 
 static int supported(const Dims& d) {
     if (d.C <= 0 || d.H <= 0 || d.D % d.H != 0) { set_error("train: bad dims"); return DYGNN_E_INVALID; }
+    if (d.C * kCoocGroups > 256) { set_error("train: channel_embedding_dim > 51 not supported"); return DYGNN_E_UNSUPPORTED; }
     if ((size_t)5 * 2 * d.Smax * 4 > 60 * 1024) { set_error("train: max_input_sequence_length too large for the embedding kernel"); return DYGNN_E_UNSUPPORTED; }
     return DYGNN_OK;
 }
@@ -761,10 +785,14 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
     // co-occurrence encoder
     if (int rc = mm(s, dX + 3 * C, D, false, PW[3], PK[3], false, F32(p.dPc), PK[3], (int)M, PK[3], C)) return rc;
     DYGNN_HIP(hipMemsetAsync(F32(p.dlut), 0, (size_t)(S + 1) * C * sizeof(float), s));
-    hipLaunchKernelGGL(k_cooc_bwd, dim3((unsigned)B), dim3(256), 0, s, F32(p.dPc), I32(p.c0), I32(p.c1), B, Ss, Sd, Ts, T, d.P, C, F32(p.dlut));
+    hipLaunchKernelGGL(k_cooc_bwd, dim3((unsigned)ceil_div(B, kPairsPerWg)), dim3(256), (size_t)kCoocGroups * kCoocRows * C * sizeof(float), s, F32(p.dPc),
+                       I32(p.c0), I32(p.c1), B, Ss, Sd, Ts, T, d.P, C, F32(p.dlut));
     DYGNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_lut_bwd, dim3(1), dim3(256), 0, s, F32(p.dlut), F32(p.hid), w->cooc_w1, S + 1, C, G(grads->cooc_w0), G(grads->cooc_b0), G(grads->cooc_w1),
-                       G(grads->cooc_b1));
+    float* dh = F32(p.dPc);        // dPc is dead now: reuse its head for dh [S+1][C]
+    hipLaunchKernelGGL(k_lut_bwd_hidden, dim3((unsigned)(S + 1)), dim3(64), 0, s, F32(p.dlut), F32(p.hid), w->cooc_w1, C, dh);
+    DYGNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_lut_bwd, dim3((unsigned)ceil_div(C * C + 2 * C, 256)), dim3(256), 0, s, F32(p.dlut), F32(p.hid), dh, S + 1, C, G(grads->cooc_w0),
+                       G(grads->cooc_b0), G(grads->cooc_w1), G(grads->cooc_b1));
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }
