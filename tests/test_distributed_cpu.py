@@ -69,3 +69,44 @@ def test_world_size_2_gloo_matches_single_process(n_batches):
         assert out[r]["num_batches"] == single["num_batches"] == n_batches
         assert abs(out[r]["average_precision"] - single["average_precision"]) < 1e-12
         assert abs(out[r]["roc_auc"] - single["roc_auc"]) < 1e-12
+
+
+def _grad_worker(rank: int, world: int, port: int, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 1))
+        net[1].bias.requires_grad_(False)                    # a frozen parameter stays out of the bucket
+        x = torch.arange(10, dtype=torch.float32).reshape(2, 5) * (rank + 1)
+        if rank == 0:
+            net(x).sum().backward()
+        else:
+            net[0](x).sum().backward()                       # rank 1 produces no gradient for net[1].weight
+        n = D.allreduce_gradients(net.parameters())
+        out[rank] = (n, [None if p.grad is None else p.grad.clone() for p in net.parameters()])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gradient_allreduce_averages_one_flat_bucket():
+    """Data-parallel training step: after the all-reduce both ranks hold the mean of the two local gradients."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_grad_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 1))
+    x = torch.arange(10, dtype=torch.float32).reshape(2, 5)
+    net(x).sum().backward()
+    g0 = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    net[0](2 * x).sum().backward()
+    g1 = [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in net.parameters()]
+    want = [(a + b) / 2 for a, b in zip(g0, g1)]
+    for r in (0, 1):
+        n, grads = out[r]
+        assert n == 5 * 3 + 3 + 3                            # weights + bias of layer 0, weight of layer 1
+        for k in (0, 1, 2):
+            assert torch.allclose(grads[k], want[k], atol=1e-6), (r, k)
+    assert D.allreduce_gradients(net.parameters()) == 0      # not initialised here: no-op
