@@ -93,9 +93,9 @@ __global__ __launch_bounds__(256) void k_mm(const MM p) {
 // (vecA / vecB), so one k-step of 16 costs a wave 8 or 6 LDS reads per 16 or 8 MFMAs instead of k_mm's 5 per 4.
 template <int WN>
 __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, const int vecB) {
-    constexpr int BM = 128, BN = 32 * WN;
-    __shared__ float As[16][BM + 16];
-    __shared__ float Bs[16][BN + 16];
+    constexpr int BM = 128, BN = 32 * WN, NB = BN / 64;
+    __shared__ float As[2][16][BM + 16];      // double buffered: the global loads of k-step t+1 fly while step t multiplies
+    __shared__ float Bs[2][16][BN + 16];
     const int z = blockIdx.z / p.ksplit, ks = blockIdx.z % p.ksplit, zb = z / p.H, zh = z % p.H;
     const float* A = p.A + zb * p.sAb + zh * p.sAh;
     const float* Bm = p.B + zb * p.sBb + zh * p.sBh;
@@ -118,61 +118,83 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
         if (n >= p.N || k >= kend) return 0.f;
         return p.transB ? Bm[(size_t)n * p.ldb + k] : Bm[(size_t)k * p.ldb + n];
     };
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        // ---- A tile: BM x 16
+    f4 ra[2], rb[NB];
+    auto fetch = [&](int k0) {                    // this thread's share of the tiles of k-step k0 -> registers
         if (p.transA) {                           // stored [K][M]: m contiguous; thread -> (k, 4 consecutive m)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int k = (tid >> 5) + 8 * e, m = (tid & 31) * 4;
-                f4 v;
-                if (vecA && m0 + m + 3 < p.M && k0 + k < kend) v = *reinterpret_cast<const f4*>(A + (size_t)(k0 + k) * p.lda + m0 + m);
-                else v = f4{ldA(m0 + m, k0 + k), ldA(m0 + m + 1, k0 + k), ldA(m0 + m + 2, k0 + k), ldA(m0 + m + 3, k0 + k)};
-                *reinterpret_cast<f4*>(&As[k][m]) = v;
+                if (vecA && m0 + m + 3 < p.M && k0 + k < kend) ra[e] = *reinterpret_cast<const f4*>(A + (size_t)(k0 + k) * p.lda + m0 + m);
+                else ra[e] = f4{ldA(m0 + m, k0 + k), ldA(m0 + m + 1, k0 + k), ldA(m0 + m + 2, k0 + k), ldA(m0 + m + 3, k0 + k)};
             }
         } else {                                  // stored [M][K]: k contiguous; thread -> (m, 4 consecutive k)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int m = (tid >> 2) + 64 * e, k = (tid & 3) * 4;
-                f4 v;
-                if (vecA && m0 + m < p.M && k0 + k + 3 < kend) v = *reinterpret_cast<const f4*>(A + (size_t)(m0 + m) * p.lda + k0 + k);
-                else v = f4{ldA(m0 + m, k0 + k), ldA(m0 + m, k0 + k + 1), ldA(m0 + m, k0 + k + 2), ldA(m0 + m, k0 + k + 3)};
-                As[k][m] = v.x; As[k + 1][m] = v.y; As[k + 2][m] = v.z; As[k + 3][m] = v.w;
+                if (vecA && m0 + m < p.M && k0 + k + 3 < kend) ra[e] = *reinterpret_cast<const f4*>(A + (size_t)(m0 + m) * p.lda + k0 + k);
+                else ra[e] = f4{ldA(m0 + m, k0 + k), ldA(m0 + m, k0 + k + 1), ldA(m0 + m, k0 + k + 2), ldA(m0 + m, k0 + k + 3)};
             }
         }
-        // ---- B tile: 16 x BN
         if (!p.transB) {                          // stored [K][N]: n contiguous
 #pragma unroll
-            for (int e = 0; e < BN / 64; ++e) {
+            for (int e = 0; e < NB; ++e) {
                 const int k = (tid / (BN / 4)) + (1024 / BN) * e, n = (tid % (BN / 4)) * 4;
-                f4 v;
-                if (vecB && n0 + n + 3 < p.N && k0 + k < kend) v = *reinterpret_cast<const f4*>(Bm + (size_t)(k0 + k) * p.ldb + n0 + n);
-                else v = f4{ldB(k0 + k, n0 + n), ldB(k0 + k, n0 + n + 1), ldB(k0 + k, n0 + n + 2), ldB(k0 + k, n0 + n + 3)};
-                *reinterpret_cast<f4*>(&Bs[k][n]) = v;
+                if (vecB && n0 + n + 3 < p.N && k0 + k < kend) rb[e] = *reinterpret_cast<const f4*>(Bm + (size_t)(k0 + k) * p.ldb + n0 + n);
+                else rb[e] = f4{ldB(k0 + k, n0 + n), ldB(k0 + k, n0 + n + 1), ldB(k0 + k, n0 + n + 2), ldB(k0 + k, n0 + n + 3)};
             }
         } else {                                  // stored [N][K]: k contiguous
 #pragma unroll
-            for (int e = 0; e < BN / 64; ++e) {
+            for (int e = 0; e < NB; ++e) {
                 const int n = (tid >> 2) + 64 * e, k = (tid & 3) * 4;
-                f4 v;
-                if (vecB && n0 + n < p.N && k0 + k + 3 < kend) v = *reinterpret_cast<const f4*>(Bm + (size_t)(n0 + n) * p.ldb + k0 + k);
-                else v = f4{ldB(k0 + k, n0 + n), ldB(k0 + k + 1, n0 + n), ldB(k0 + k + 2, n0 + n), ldB(k0 + k + 3, n0 + n)};
-                Bs[k][n] = v.x; Bs[k + 1][n] = v.y; Bs[k + 2][n] = v.z; Bs[k + 3][n] = v.w;
+                if (vecB && n0 + n < p.N && k0 + k + 3 < kend) rb[e] = *reinterpret_cast<const f4*>(Bm + (size_t)(n0 + n) * p.ldb + k0 + k);
+                else rb[e] = f4{ldB(k0 + k, n0 + n), ldB(k0 + k + 1, n0 + n), ldB(k0 + k + 2, n0 + n), ldB(k0 + k + 3, n0 + n)};
             }
         }
-        __syncthreads();
+    };
+    auto stash = [&](int buf) {                   // registers -> LDS tile `buf` (k-major)
+        if (p.transA) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) *reinterpret_cast<f4*>(&As[buf][(tid >> 5) + 8 * e][(tid & 31) * 4]) = ra[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int m = (tid >> 2) + 64 * e, k = (tid & 3) * 4;
+                As[buf][k][m] = ra[e].x; As[buf][k + 1][m] = ra[e].y; As[buf][k + 2][m] = ra[e].z; As[buf][k + 3][m] = ra[e].w;
+            }
+        }
+        if (!p.transB) {
+#pragma unroll
+            for (int e = 0; e < NB; ++e) *reinterpret_cast<f4*>(&Bs[buf][(tid / (BN / 4)) + (1024 / BN) * e][(tid % (BN / 4)) * 4]) = rb[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const int n = (tid >> 2) + 64 * e, k = (tid & 3) * 4;
+                Bs[buf][k][n] = rb[e].x; Bs[buf][k + 1][n] = rb[e].y; Bs[buf][k + 2][n] = rb[e].z; Bs[buf][k + 3][n] = rb[e].w;
+            }
+        }
+    };
+    fetch(kbeg);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        const bool more = k0 + 16 < kend;
+        if (more) fetch(k0 + 16);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             float a[4], b[WN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[4 * kk + g][64 * wy + 16 * i + c];
+            for (int i = 0; i < 4; ++i) a[i] = As[buf][4 * kk + g][64 * wy + 16 * i + c];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = Bs[4 * kk + g][16 * WN * wx + 16 * j + c];
+            for (int j = 0; j < WN; ++j) b[j] = Bs[buf][4 * kk + g][16 * WN * wx + 16 * j + c];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (more) stash(buf ^ 1);                 // the other buffer was last read one iteration ago, before the barrier below
         __syncthreads();
+        buf ^= 1;
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
