@@ -197,7 +197,7 @@ extern "C" int dygnn_merge_layer_sigmoid(const float* a, const float* b, int64_t
     DYGNN_REQUIRE(n >= 0 && dim > 0 && hidden > 0, "merge_layer: bad sizes");
     DYGNN_REQUIRE(n == 0 || (a && b && fc1_w && fc1_b && fc2_w && fc2_b && out), "merge_layer: null pointer");
     if (n == 0) return DYGNN_OK;
-    if (dim % 4 == 0) {
+    if (dim % 4 == 0 && n >= 2048) {        // few rows: the one-workgroup-per-row kernel below has the shorter critical path
         hipLaunchKernelGGL(k_merge_sigmoid_mfma, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, as_stream(stream), a, b, n, dim, hidden,
                            fc1_w, fc1_b, fc2_w, fc2_b, out);
         DYGNN_LAUNCH_CHECK();

@@ -10,6 +10,7 @@
 // them as constants, models/DyGFormer.py:28-29).
 // This is the first, unfused version (correctness + a working training loop); inference uses dygformer_fused3.hip.
 #include "dygformer_layout.h"
+#include "gemm.h"
 
 namespace dygnn {
 
@@ -215,9 +216,8 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
     }
 }
 
-static int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb, bool tB, float* C, int ldc, int M, int N, int K,
-              const float* bias = nullptr, float alpha = 1.f, float beta = 0.f, int batch = 1, int H = 1, int64_t sAb = 0, int64_t sAh = 0,
-              int64_t sBb = 0, int64_t sBh = 0, int64_t sCb = 0, int64_t sCh = 0) {
+int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb, bool tB, float* C, int ldc, int M, int N, int K, const float* bias, float alpha,
+       float beta, int batch, int H, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh) {
     if (M <= 0 || N <= 0 || batch <= 0) return DYGNN_OK;
     MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh, 1, K};
     // weight gradients: small output, K = all rows of the call -> split K over workgroups, partial sums meet by atomicAdd

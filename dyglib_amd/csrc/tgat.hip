@@ -10,6 +10,7 @@
 // This round's version keeps the per-layer activations in HBM (correctness + first measurement); fusing the gather with
 // the K/V GEMM is the next step.
 #include "common.h"
+#include "gemm.h"
 
 namespace dygnn {
 
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256) void k_tgat_inputs(const float* __restrict__ h
 // all 8 waves, so they are staged through an LDS ring by LDS-DMA (8 k-chunks deep) and every fragment read feeds 8
 // MFMAs; the B operand is gathered straight from the tables / computed (time encoding) four chunks ahead.
 // ------------------------------------------------------------------------------------------------
+constexpr int64_t kLinAttnMinRows = 32768;   // levels with at least this many neighbour rows use the linearity-based attention
 constexpr int kKvNT = 17;            // column tiles per workgroup (Dq <= 272)
 constexpr int kKvSlots = 8;          // ring depth in k-chunks
 constexpr int kKvLds = kKvSlots * kKvNT * 1024;
@@ -367,6 +369,97 @@ __global__ __launch_bounds__(256) void k_tgat_attention(const float* __restrict_
     if (v1) o4[x1] = ob;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Attention over the k neighbours WITHOUT materialising K and V.  The key / value projections are bias-free linear maps
+// (models/modules.py:126-128), so
+//     score_ijh = q_ih . (W_k,h x_ij) = (W_k,h^T q_ih) . x_ij          and          o_ih = sum_j p_ijh (W_v,h x_ij) = W_v,h (sum_j p_ijh x_ij)
+// with x_ij = [h(nbr) | edge | cos(w dt + b)] the neighbour's input row: the two [n*k, 444] x [444, 272] products (81 GFLOP per
+// layer-1 pass at Reddit size) become two [n, 136] x [136, 444] products per head (4 GFLOP) around this kernel, which is
+// bound by gathering the input rows twice.  One wave per node; lanes sweep a row as float4 (Dkv/4 <= 128 columns).
+// qk [n][H][Dkv] = W_k,h^T q_ih ; z [n][H][Dkv] = sum_j p_ijh x_ij.
+// ------------------------------------------------------------------------------------------------
+template <int KCACHE>      // > 0: the k <= KCACHE input rows stay in registers between the score pass and the weighted sum (one gather)
+__global__ __launch_bounds__(256) void k_tgat_attn_lin(const float* __restrict__ qk, const float* __restrict__ h_lower, const float* __restrict__ node_feat,
+                                                         const float* __restrict__ edge_feat, const int32_t* __restrict__ lower_ids,
+                                                         const int32_t* __restrict__ nbr_eid, const float* __restrict__ nbr_dt, const float* __restrict__ tw,
+                                                         const float* __restrict__ tb, int64_t n, int k, int Fn, int Fe, int Ft, int H, float scale,
+                                                         float* __restrict__ z) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= n) return;
+    float* pw = reinterpret_cast<float*>(smem) + wave * H * k;       // [H][k] scores -> probabilities
+    const int Dkv = Fn + Fe + Ft, D4 = Dkv >> 2;
+    const int x0 = lane, x1 = lane + 64;
+    const bool v0 = x0 < D4, v1 = x1 < D4;
+    auto fetch = [&](int64_t r, int x) -> f4 {                       // float4 column x of the input row of neighbour entry r
+        const int kk = 4 * x;
+        if (kk < Fn) {
+            const int64_t le = n + r;
+            const float* hp = h_lower ? h_lower + le * Fn : node_feat + (size_t)lower_ids[le] * Fn;
+            return *reinterpret_cast<const f4*>(hp + kk);
+        }
+        if (kk < Fn + Fe) return *reinterpret_cast<const f4*>(edge_feat + (size_t)nbr_eid[r] * Fe + (kk - Fn));
+        const int f = kk - Fn - Fe;
+        const float dt = nbr_dt[r];
+        const f4 w = *reinterpret_cast<const f4*>(tw + f), b = *reinterpret_cast<const f4*>(tb + f);
+        return f4{cos_time_t(fmaf(dt, w.x, b.x)), cos_time_t(fmaf(dt, w.y, b.y)), cos_time_t(fmaf(dt, w.z, b.z)), cos_time_t(fmaf(dt, w.w, b.w))};
+    };
+    auto dot4 = [](const f4 a, const f4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); };
+    const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+    f4 xs[KCACHE > 0 ? KCACHE : 1][2];
+#pragma unroll
+    for (int j = 0; j < (KCACHE > 0 ? KCACHE : 1 << 30); ++j) {
+        if (j >= k) break;
+        const int64_t r = i * k + j;
+        const f4 xa = v0 ? fetch(r, x0) : zero, xb = v1 ? fetch(r, x1) : zero;
+        if (KCACHE > 0) { xs[j][0] = xa; xs[j][1] = xb; }
+        for (int h = 0; h < H; ++h) {
+            const f4* qh = reinterpret_cast<const f4*>(qk + ((size_t)i * H + h) * Dkv);
+            float sc = (v0 ? dot4(qh[x0], xa) : 0.f) + (v1 ? dot4(qh[x1], xb) : 0.f);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o, 64);
+            if (lane == 0) {
+                sc *= scale;                                              // modules.py:173
+                if (lower_ids[n + r] == 0) sc = -1e10f;                   // modules.py:176-184
+                pw[h * k + j] = sc;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < H) {
+        float mx = -INFINITY;
+        for (int j = 0; j < k; ++j) mx = fmaxf(mx, pw[lane * k + j]);
+        float sum = 0.f;
+        for (int j = 0; j < k; ++j) { const float e = expf(pw[lane * k + j] - mx); pw[lane * k + j] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < k; ++j) pw[lane * k + j] *= inv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int h = 0; h < H; ++h) {
+        f4 za = zero, zb = zero;
+#pragma unroll
+        for (int j = 0; j < (KCACHE > 0 ? KCACHE : 1 << 30); ++j) {
+            if (j >= k) break;
+            const int64_t r = i * k + j;
+            const float p = pw[h * k + j];
+            if (KCACHE > 0) {
+                const f4 xa = xs[j][0], xb = xs[j][1];
+                za.x = fmaf(p, xa.x, za.x); za.y = fmaf(p, xa.y, za.y); za.z = fmaf(p, xa.z, za.z); za.w = fmaf(p, xa.w, za.w);
+                zb.x = fmaf(p, xb.x, zb.x); zb.y = fmaf(p, xb.y, zb.y); zb.z = fmaf(p, xb.z, zb.z); zb.w = fmaf(p, xb.w, zb.w);
+                continue;
+            }
+            if (v0) { const f4 xv = fetch(r, x0); za.x = fmaf(p, xv.x, za.x); za.y = fmaf(p, xv.y, za.y); za.z = fmaf(p, xv.z, za.z); za.w = fmaf(p, xv.w, za.w); }
+            if (v1) { const f4 xv = fetch(r, x1); zb.x = fmaf(p, xv.x, zb.x); zb.y = fmaf(p, xv.y, zb.y); zb.z = fmaf(p, xv.z, zb.z); zb.w = fmaf(p, xv.w, zb.w); }
+        }
+        f4* zo = reinterpret_cast<f4*>(z + ((size_t)i * H + h) * Dkv);
+        if (v0) zo[x0] = za;
+        if (v1) zo[x1] = zb;
+    }
+}
+
 // y = LayerNorm(fc_out + residual) (models/modules.py:196-199), written into the first Dq columns of the MergeLayer input
 // row [Dq + Fn]; the raw node features fill the rest (models/TGAT.py:134, models/modules.py:64)
 __global__ __launch_bounds__(256) void k_tgat_post(const float* __restrict__ fc_out, const float* __restrict__ q_in, const float* __restrict__ gamma,
@@ -411,7 +504,7 @@ struct TgatPlan {
     int64_t n[DYGNN_MAX_LAYERS + 1];       // level sizes: n[L] = 2B, n[l-1] = n[l] * (1 + k)
     // byte offsets
     size_t ids[DYGNN_MAX_LAYERS + 1], times[DYGNN_MAX_LAYERS + 1], eid[DYGNN_MAX_LAYERS + 1], dt[DYGNN_MAX_LAYERS + 1], h[DYGNN_MAX_LAYERS + 1];
-    size_t kv_in, q_in, kv, q, att, fc, merge_in, hid, kvw, total;
+    size_t kv_in, q_in, kv, q, att, fc, merge_in, hid, kvw, qk, z, total;
     int KC;
 };
 
@@ -435,7 +528,13 @@ static TgatPlan make_tgat_plan(const dygnn_tgat_config& c, int64_t B) {
     p.KC = (p.Dkv + 15) / 16;
     p.kvw = take((size_t)2 * p.KC * kKvNT * 256 * sizeof(float));      // packed key/value weights of the layer being evaluated
     p.q_in = take((size_t)nmax * p.Dq * sizeof(float));
-    p.kv = take((size_t)nmax * p.k * 2 * p.Dq * sizeof(float));
+    {   // K | V of the largest level that still takes the fused K/V kernel (levels of >= kLinAttnMinRows rows never materialise them)
+        int64_t small = 0;
+        for (int l = 1; l <= p.L; ++l) if (p.n[l] * p.k < kLinAttnMinRows && p.n[l] > small) small = p.n[l];
+        p.kv = take((size_t)small * p.k * 2 * p.Dq * sizeof(float));
+    }
+    p.qk = take((size_t)nmax * p.H * p.Dkv * sizeof(float));
+    p.z = take((size_t)nmax * p.H * p.Dkv * sizeof(float));
     p.q = take((size_t)nmax * p.Dq * sizeof(float));
     p.att = take((size_t)nmax * p.Dq * sizeof(float));
     p.fc = take((size_t)nmax * p.Dq * sizeof(float));
@@ -522,8 +621,25 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
         hipLaunchKernelGGL(k_tgat_inputs, dim3((unsigned)n), dim3(256), 0, s, h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]),
                            F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, (float*)nullptr, F32(p.q_in));     // query rows
         DYGNN_LAUNCH_CHECK();
-        // K and V projections (bias-free, modules.py:126-128) write the two halves of one [n*k][2*Dq] buffer
-        {
+        if (int rc = gemm_nt<false>(F32(p.q_in), Lw.query_w, nullptr, F32(p.q), n, p.Dq, p.Dq, p.Dq, s)) return rc;
+        if (n * p.k >= kLinAttnMinRows) {
+            // qk[i][h] = W_k,h^T q_ih : per head [n][hd] x [hd][Dkv] (rows h*hd .. of key_w), one batched launch over the heads
+            if (int rc = train::mm(s, F32(p.q), p.Dq, false, Lw.key_w, p.Dkv, false, F32(p.qk), p.H * p.Dkv, (int)n, p.Dkv, p.hd, nullptr, 1.f, 0.f, p.H, p.H, 0, p.hd,
+                                   0, (int64_t)p.hd * p.Dkv, 0, p.Dkv)) return rc;
+            const dim3 grid((unsigned)ceil_div(n, 4));
+            const size_t lds = (size_t)4 * p.H * p.k * sizeof(float);
+            if (p.k <= 20)
+                hipLaunchKernelGGL((k_tgat_attn_lin<20>), grid, dim3(256), lds, s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]), F32(p.dt[l]),
+                                   w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z));
+            else
+                hipLaunchKernelGGL((k_tgat_attn_lin<0>), grid, dim3(256), lds, s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]), F32(p.dt[l]),
+                                   w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z));
+            DYGNN_LAUNCH_CHECK();
+            // att[i][h*hd ..] = W_v,h z_ih : per head [n][Dkv] x [Dkv][hd]
+            if (int rc = train::mm(s, F32(p.z), p.H * p.Dkv, false, Lw.value_w, p.Dkv, true, F32(p.att), p.Dq, (int)n, p.hd, p.Dkv, nullptr, 1.f, 0.f, p.H, p.H, 0, p.Dkv,
+                                   0, (int64_t)p.hd * p.Dkv, 0, p.hd)) return rc;
+        } else {
+            // small levels (the top TGAT layer, TGN's single layer): K and V by the fused gather + projection kernel, then attention
             const int64_t tot = (int64_t)2 * p.KC * kKvNT * 256;
             hipLaunchKernelGGL(k_pack_kv, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s, Lw.key_w, Lw.value_w, p.Dq, p.Dkv, p.KC, F32(p.kvw));
             DYGNN_LAUNCH_CHECK();
@@ -535,11 +651,10 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
             hipLaunchKernelGGL(k_tgat_kv, dim3((unsigned)ceil_div(n * p.k, 256), 2), dim3(512), kKvLds, s, h_lower, node_feat, edge_feat, I32(p.ids[l - 1]),
                                I32(p.eid[l]), F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, F32(p.kvw), p.KC, p.Dq, F32(p.kv));
             DYGNN_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_tgat_attention, dim3((unsigned)ceil_div(n, 4)), dim3(256), (size_t)4 * p.H * p.k * sizeof(float), s, F32(p.q), F32(p.kv),
+                               I32(p.ids[l - 1]), n, p.k, p.H, p.hd, scale, F32(p.att));
+            DYGNN_LAUNCH_CHECK();
         }
-        if (int rc = gemm_nt<false>(F32(p.q_in), Lw.query_w, nullptr, F32(p.q), n, p.Dq, p.Dq, p.Dq, s)) return rc;
-        hipLaunchKernelGGL(k_tgat_attention, dim3((unsigned)ceil_div(n, 4)), dim3(256), (size_t)4 * p.H * p.k * sizeof(float), s, F32(p.q), F32(p.kv),
-                           I32(p.ids[l - 1]), n, p.k, p.H, p.hd, scale, F32(p.att));
-        DYGNN_LAUNCH_CHECK();
         if (int rc = gemm_nt<false>(F32(p.att), Lw.res_w, Lw.res_b, F32(p.fc), n, p.Dq, p.Dq, p.Dq, s)) return rc;
         hipLaunchKernelGGL(k_tgat_post, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, s, F32(p.fc), F32(p.q_in), Lw.ln_w, Lw.ln_b, node_feat, I32(p.ids[l - 1]),
                            n, p.Dq, p.Fn, F32(p.merge_in));
