@@ -92,9 +92,9 @@ __global__ __launch_bounds__(256) void k_mm(const MM p) {
 // The large products: 128 x (32*WN) tile per workgroup, 4 waves as 2 x 2, each wave 4 x WN accumulator tiles; operands go
 // through LDS in k-major layout ([16 k][tile + 4]) with float4 global loads when pointers / leading dimensions allow
 // (vecA / vecB), so one k-step of 16 costs a wave 8 or 6 LDS reads per 16 or 8 MFMAs instead of k_mm's 5 per 4.
-template <int WN>
+template <int WN, int WM>
 __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, const int vecB) {
-    constexpr int BM = 128, BN = 32 * WN, NB = BN / 64;
+    constexpr int BM = 32 * WM, BN = 32 * WN, NB = BN / 64, NA = BM / 64;      // tile BM x BN; wave = WM x WN accumulator tiles
     __shared__ float As[2][16][BM + 16];      // double buffered: the global loads of k-step t+1 fly while step t multiplies
     __shared__ float Bs[2][16][BN + 16];
     const int z = blockIdx.z / p.ksplit, ks = blockIdx.z % p.ksplit, zb = z / p.H, zh = z % p.H;
@@ -106,9 +106,9 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave >> 1, wx = wave & 1;
     const int c = lane & 15, g = lane >> 4;
-    f4 acc[4][WN];
+    f4 acc[WM][WN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     auto ldA = [&](int m, int k) -> float {      // op(A)[m][k], zero outside
@@ -119,18 +119,18 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
         if (n >= p.N || k >= kend) return 0.f;
         return p.transB ? Bm[(size_t)n * p.ldb + k] : Bm[(size_t)k * p.ldb + n];
     };
-    f4 ra[2], rb[NB];
+    f4 ra[NA], rb[NB];
     auto fetch = [&](int k0) {                    // this thread's share of the tiles of k-step k0 -> registers
         if (p.transA) {                           // stored [K][M]: m contiguous; thread -> (k, 4 consecutive m)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int k = (tid >> 5) + 8 * e, m = (tid & 31) * 4;
+            for (int e = 0; e < NA; ++e) {
+                const int k = (tid / (BM / 4)) + (1024 / BM) * e, m = (tid % (BM / 4)) * 4;
                 if (vecA && m0 + m + 3 < p.M && k0 + k < kend) ra[e] = *reinterpret_cast<const f4*>(A + (size_t)(k0 + k) * p.lda + m0 + m);
                 else ra[e] = f4{ldA(m0 + m, k0 + k), ldA(m0 + m + 1, k0 + k), ldA(m0 + m + 2, k0 + k), ldA(m0 + m + 3, k0 + k)};
             }
         } else {                                  // stored [M][K]: k contiguous; thread -> (m, 4 consecutive k)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < NA; ++e) {
                 const int m = (tid >> 2) + 64 * e, k = (tid & 3) * 4;
                 if (vecA && m0 + m < p.M && k0 + k + 3 < kend) ra[e] = *reinterpret_cast<const f4*>(A + (size_t)(m0 + m) * p.lda + k0 + k);
                 else ra[e] = f4{ldA(m0 + m, k0 + k), ldA(m0 + m, k0 + k + 1), ldA(m0 + m, k0 + k + 2), ldA(m0 + m, k0 + k + 3)};
@@ -155,10 +155,10 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
     auto stash = [&](int buf) {                   // registers -> LDS tile `buf` (k-major)
         if (p.transA) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) *reinterpret_cast<f4*>(&As[buf][(tid >> 5) + 8 * e][(tid & 31) * 4]) = ra[e];
+            for (int e = 0; e < NA; ++e) *reinterpret_cast<f4*>(&As[buf][(tid / (BM / 4)) + (1024 / BM) * e][(tid % (BM / 4)) * 4]) = ra[e];
         } else {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < NA; ++e) {
                 const int m = (tid >> 2) + 64 * e, k = (tid & 3) * 4;
                 As[buf][k][m] = ra[e].x; As[buf][k + 1][m] = ra[e].y; As[buf][k + 2][m] = ra[e].z; As[buf][k + 3][m] = ra[e].w;
             }
@@ -183,13 +183,13 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
         if (more) fetch(k0 + 16);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            float a[4], b[WN];
+            float a[WM], b[WN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[buf][4 * kk + g][64 * wy + 16 * i + c];
+            for (int i = 0; i < WM; ++i) a[i] = As[buf][4 * kk + g][16 * WM * wy + 16 * i + c];
 #pragma unroll
             for (int j = 0; j < WN; ++j) b[j] = Bs[buf][4 * kk + g][16 * WN * wx + 16 * j + c];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
@@ -203,10 +203,10 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
         if (n >= p.N) continue;
         const float bv = (p.bias && ks == 0) ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 64 * wy + 16 * i + 4 * g + r;
+                const int m = m0 + 16 * WM * wy + 16 * i + 4 * g + r;
                 if (m >= p.M) continue;
                 float v = p.alpha * acc[i][j][r] + bv;
                 if (p.ksplit > 1) { atomicAdd(&C[(size_t)m * p.ldc + n], v); continue; }
@@ -231,8 +231,16 @@ int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb,
     if (M >= 128 && N >= 48) {
         const int vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && lda % 4 == 0 && sAb % 4 == 0 && sAh % 4 == 0) ? 1 : 0;
         const int vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && ldb % 4 == 0 && sBb % 4 == 0 && sBh % 4 == 0) ? 1 : 0;
-        if (N > 64) hipLaunchKernelGGL((k_mm_big<4>), dim3((unsigned)ceil_div(M, 128), (unsigned)ceil_div(N, 128), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
-        else hipLaunchKernelGGL((k_mm_big<2>), dim3((unsigned)ceil_div(M, 128), (unsigned)ceil_div(N, 64), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
+        // mid-size products (a few hundred 128-row tiles at most): 64-row tiles put 2-4 workgroups on every CU, which hides
+        // the per-k-step load latency that a single resident workgroup exposes
+        const bool small_grid = ceil_div(M, 128) * ceil_div(N, N > 64 ? 128 : 64) * batch < 512;
+        if (N > 64) {
+            if (small_grid) hipLaunchKernelGGL((k_mm_big<4, 2>), dim3((unsigned)ceil_div(M, 64), (unsigned)ceil_div(N, 128), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
+            else hipLaunchKernelGGL((k_mm_big<4, 4>), dim3((unsigned)ceil_div(M, 128), (unsigned)ceil_div(N, 128), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
+        } else {
+            if (small_grid) hipLaunchKernelGGL((k_mm_big<2, 2>), dim3((unsigned)ceil_div(M, 64), (unsigned)ceil_div(N, 64), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
+            else hipLaunchKernelGGL((k_mm_big<2, 4>), dim3((unsigned)ceil_div(M, 128), (unsigned)ceil_div(N, 64), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
+        }
         DYGNN_LAUNCH_CHECK();
         return DYGNN_OK;
     }
