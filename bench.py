@@ -52,6 +52,68 @@ def flops_per_pair(S_s: int, S_d: int, P: int, Fn=172, Ft=100, C=50, layers=2) -
             + layers * (T * (2 * D * 3 * D + 2 * D * D + 4 * D * 4 * D) + 4 * T * T * D) + 2 * 2 * D * Fn)
 
 
+# ---- CPU-baseline legs of the secondary benchmarks (tools/bench_tgat.py, bench_tgn.py, bench_train.py).  They live here because
+# bench.py's cpu_baseline leg is the only non-test code allowed to execute anything under oracle/.
+def cpu_baseline_tgat(data, nf, ef, params, host_batches, k: int, steps: int, B: int) -> dict:
+    from oracle import dygformer_oracle as orc, tgat_oracle as torc
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    nft, eft = torch.from_numpy(nf), torch.from_numpy(ef)
+    tp = {kk: torch.from_numpy(v) for kk, v in params.items()}
+    t0 = time.perf_counter()
+    for i in range(steps):
+        s, d, n, t = host_batches[i]
+        torc.tgat_forward(tp, nft, eft, adj, s, d, t, 2, k, 2)
+        torc.tgat_forward(tp, nft, eft, adj, s, n, t, 2, k, 2)
+    cel = time.perf_counter() - t0
+    return {"value": round(steps * B / cel, 1), "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} of the same steps ({cel:.1f} s), oracle/tgat_oracle.py"}
+
+
+def cpu_baseline_tgn(data, nf, ef, params, host_batches, k: int, steps: int, B: int) -> dict:
+    from oracle import dygformer_oracle as orc, tgn_oracle as tn
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    nft, eft = torch.from_numpy(nf), torch.from_numpy(ef)
+    tp = {kk: torch.from_numpy(v) for kk, v in params.items()}
+    st = tn.TgnState(nf.shape[0], 172)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        s, d, ng, t, e = host_batches[i]
+        tn.tgn_forward(tp, nft, eft, adj, st, s, ng, t, None, False, 1, k, 2)
+        tn.tgn_forward(tp, nft, eft, adj, st, s, d, t, e, True, 1, k, 2)
+    cel = time.perf_counter() - t0
+    return {"value": round(steps * B / cel, 1), "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"the first {steps} steps ({cel:.1f} s), oracle/tgn_oracle.py"}
+
+
+def cpu_baseline_train(data, nf, ef, params, mparams, batch_fn, P: int, L: int, steps: int, B: int) -> dict:
+    """the training step (pos + neg forward, BCE, backward, Adam) through torch autograd over the oracle"""
+    from oracle import dygformer_oracle as orc
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cp = {kk: torch.from_numpy(v.copy()).requires_grad_(True) for kk, v in params.items()}
+    cm = {kk: torch.from_numpy(v.copy()).requires_grad_(True) for kk, v in mparams.items()}
+    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    copt = torch.optim.Adam(list(cp.values()) + list(cm.values()), lr=1e-4)
+
+    def cpu_step(i):
+        src, dst, neg, t = batch_fn(i)
+        ps, pd = orc.dygformer_forward(cp, nf, ef, adj, src, dst, t, P, L)
+        ns, nd = orc.dygformer_forward(cp, nf, ef, adj, src, neg, t, P, L)
+        pos, ng = orc.merge_layer(cm, ps, pd).squeeze(-1).sigmoid(), orc.merge_layer(cm, ns, nd).squeeze(-1).sigmoid()
+        loss = torch.nn.functional.binary_cross_entropy(torch.cat([pos, ng]), torch.cat([torch.ones_like(pos), torch.zeros_like(ng)]))
+        copt.zero_grad()
+        loss.backward()
+        copt.step()
+    cpu_step(0)
+    c0 = time.perf_counter()
+    for i in range(steps):
+        cpu_step(1 + i)
+    csec = (time.perf_counter() - c0) / steps
+    return {"value": round(B / csec, 1), "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} of the same steps ({csec * steps:.1f} s) through oracle autograd"}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

@@ -45,16 +45,6 @@ out = {"metric": "edges/sec (link-prediction fwd) TGAT Reddit-shaped", "value": 
        "roofline": {"note": "achieved = the REFERENCE formulation's 179.4 GFLOP per step / time; the kernels execute ~20x fewer (K/V never materialised)", "bound": "mfma", "achieved": round(179.4e9 / (el / args.steps) / 1e12, 3), "peak": 157.3, "unit": "TFLOP/s",
                     "frac": round(179.4e9 / (el / args.steps) / 157.3e12, 4), "traffic": None}}
 if args.cpu_steps > 0:
-    from oracle import dygformer_oracle as orc, tgat_oracle as torc
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
-    nft, eft = torch.from_numpy(nf), torch.from_numpy(ef)
-    tp = {k: torch.from_numpy(v) for k, v in params.items()}
-    t0 = time.perf_counter()
-    for i in range(args.cpu_steps):
-        s, d, n, t = [x.cpu().numpy() for x in batches[i]]
-        torc.tgat_forward(tp, nft, eft, adj, s, d, t, 2, K, 2); torc.tgat_forward(tp, nft, eft, adj, s, n, t, 2, K, 2)
-    cel = time.perf_counter() - t0
-    out["cpu_baseline"] = {"value": round(args.cpu_steps * B / cel, 1), "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
-                           "sample": f"{args.cpu_steps} of the same steps ({cel:.1f} s), oracle/tgat_oracle.py"}
+    import bench                                   # the CPU-baseline leg lives in bench.py (the only non-test user of oracle/)
+    out["cpu_baseline"] = bench.cpu_baseline_tgat(data, nf, ef, params, [[x.cpu().numpy() for x in b] for b in batches[:args.cpu_steps]], K, args.cpu_steps, B)
 print(json.dumps(out))

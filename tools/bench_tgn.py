@@ -40,17 +40,6 @@ out = {"metric": "edges/sec (link-prediction fwd) TGN MOOC-shaped", "value": rou
        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "dtype": "f32", "data": "synthetic", "scaling": "replicas only",
        "config": {"workload": "TGN link-prediction forward, synthetic MOOC-shaped graph (7047+97 nodes, 411749 edges), k=10, 1 layer, batch=200, sequential batches"}}
 if args.cpu_steps > 0:
-    from oracle import dygformer_oracle as orc, tgn_oracle as tn
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
-    nft, eft = torch.from_numpy(nf), torch.from_numpy(ef)
-    tp = {k: torch.from_numpy(v) for k, v in params.items()}
-    st = tn.TgnState(nf.shape[0], 172)
-    t0 = time.perf_counter()
-    for i in range(args.cpu_steps):
-        s, d, ng, t, e = host[i]
-        tn.tgn_forward(tp, nft, eft, adj, st, s, ng, t, None, False, 1, K, 2); tn.tgn_forward(tp, nft, eft, adj, st, s, d, t, e, True, 1, K, 2)
-    cel = time.perf_counter() - t0
-    out["cpu_baseline"] = {"value": round(args.cpu_steps * B / cel, 1), "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
-                           "sample": f"the first {args.cpu_steps} steps ({cel:.1f} s), oracle/tgn_oracle.py"}
+    import bench                                   # the CPU-baseline leg lives in bench.py (the only non-test user of oracle/)
+    out["cpu_baseline"] = bench.cpu_baseline_tgn(data, nf, ef, params, host, K, args.cpu_steps, B)
 print(json.dumps(out))

@@ -12,7 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dyglib_amd import DyGFormer, MergeLayer, get_neighbor_sampler, synthetic as syn  # noqa: E402
-from oracle import dygformer_oracle as orc  # noqa: E402  (CPU baseline only)
+import bench  # noqa: E402  (its cpu_baseline leg is the only non-test user of oracle/)
 
 dev = "cuda:0"
 B, L, P = 200, 64, 2
@@ -60,29 +60,7 @@ torch.cuda.synchronize()
 sec = (time.perf_counter() - t0) / steps
 
 # CPU baseline: the same step through the oracle's autograd (torch CPU, 16 threads), 2 steps
-torch.set_num_threads(min(16, os.cpu_count() or 1))
-cp = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in params.items()}
-cm = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in mparams.items()}
-adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
-copt = torch.optim.Adam(list(cp.values()) + list(cm.values()), lr=1e-4)
-
-
-def cpu_step(i):
-    src, dst, neg, t = batch(i)
-    ps, pd = orc.dygformer_forward(cp, nf, ef, adj, src, dst, t, P, L)
-    ns, nd = orc.dygformer_forward(cp, nf, ef, adj, src, neg, t, P, L)
-    pos, ng = orc.merge_layer(cm, ps, pd).squeeze(-1).sigmoid(), orc.merge_layer(cm, ns, nd).squeeze(-1).sigmoid()
-    loss = torch.nn.functional.binary_cross_entropy(torch.cat([pos, ng]), torch.cat([torch.ones_like(pos), torch.zeros_like(ng)]))
-    copt.zero_grad(); loss.backward(); copt.step()
-
-
-cpu_step(0)
-c0 = time.perf_counter()
-ncpu = 2
-for i in range(ncpu):
-    cpu_step(1 + i)
-csec = (time.perf_counter() - c0) / ncpu
+cpu = bench.cpu_baseline_train(data, nf, ef, params, mparams, batch, P, L, 2, B)
 print(json.dumps({"metric": "edges/sec (link-prediction TRAIN step: fwd pos+neg, bwd, Adam) DyGFormer Wikipedia-shaped", "value": round(B / sec, 1),
                   "unit": "edges/s", "ms_per_step": round(sec * 1e3, 3), "steps": steps, "dtype": "f32", "dropout": 0.1, "final_loss": round(float(loss.detach()), 4),
-                  "cpu_baseline": {"value": round(B / csec, 1), "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
-                                   "sample": f"{ncpu} of the same steps ({csec * ncpu:.1f} s) through oracle autograd"}}))
+                  "cpu_baseline": cpu}))
