@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported first: see module docstring)
 from . import _build
 
 DYGNN_MAX_LAYERS = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -64,6 +64,11 @@ class TgatWeights(C.Structure):
     _fields_ = [("time_w", C.c_void_p), ("time_b", C.c_void_p), ("layers", TgatLayerWeights * DYGNN_MAX_LAYERS)]
 
 
+class TgatLevels(C.Structure):
+    _fields_ = [("ids", C.c_void_p * (DYGNN_MAX_LAYERS + 1)), ("nbr_eid", C.c_void_p * (DYGNN_MAX_LAYERS + 1)),
+                ("nbr_dt", C.c_void_p * (DYGNN_MAX_LAYERS + 1))]
+
+
 class GruWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
 
@@ -104,6 +109,8 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(DygformerTaps),
                                           C.c_int32, C.c_void_p]),
     "dygnn_tgat_workspace_bytes": (C.c_size_t, [C.POINTER(TgatConfig), C.c_int64]),
+    "dygnn_tgat_forward_levels": (C.c_int, [C.POINTER(TgatConfig), C.POINTER(TgatWeights), C.POINTER(TgatLevels), C.c_void_p, C.c_void_p, C.c_int64,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dygnn_tgat_forward": (C.c_int, [C.POINTER(TgatConfig), C.POINTER(TgatWeights), C.POINTER(Csr), C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dygnn_tgn_workspace_bytes": (C.c_size_t, [C.POINTER(TgatConfig), C.c_int64, C.c_int64]),

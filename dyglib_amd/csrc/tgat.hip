@@ -581,13 +581,14 @@ extern "C" size_t dygnn_tgat_workspace_bytes(const dygnn_tgat_config* cfg, int64
 namespace dygnn {
 static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_csr* csr, const float* node_feat,
                              const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
-                             float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
+                             float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream,
+                             const dygnn_tgat_levels* levels = nullptr) {
     if (int rc = check_tgat(cfg)) return rc;
     DYGNN_REQUIRE(w && w->time_w && w->time_b, "tgat: null weights");
-    DYGNN_REQUIRE(csr && csr->indptr && csr->num_nodes >= 1, "tgat: bad csr");
+    DYGNN_REQUIRE(levels || (csr && csr->indptr && csr->num_nodes >= 1), "tgat: bad csr");
     DYGNN_REQUIRE(batch >= 0 && node_feat && edge_feat, "tgat: bad arguments");
     if (batch == 0) return DYGNN_OK;
-    DYGNN_REQUIRE(src && dst && times && out_src && out_dst && workspace, "tgat: null pointer");
+    DYGNN_REQUIRE((levels || (src && dst && times)) && out_src && out_dst && workspace, "tgat: null pointer");
     const TgatPlan p = make_tgat_plan(*cfg, batch);
     if (workspace_bytes < p.total) {
         set_error("tgat: workspace too small (%zu < %zu bytes)", workspace_bytes, p.total);
@@ -604,6 +605,17 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
     auto F64 = [&](size_t off) { return reinterpret_cast<double*>(ws + off); };
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
 
+    if (levels) {
+        // pre-sampled levels (random strategies): copy them where the sampling kernels would have written them
+        for (int l = 0; l <= p.L; ++l) {
+            DYGNN_REQUIRE(levels->ids[l] && (l == 0 || (levels->nbr_eid[l] && levels->nbr_dt[l])), "tgat: null level array (level %d)", l);
+            DYGNN_HIP(hipMemcpyAsync(I32(p.ids[l]), levels->ids[l], (size_t)p.n[l] * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+            if (l >= 1) {
+                DYGNN_HIP(hipMemcpyAsync(I32(p.eid[l]), levels->nbr_eid[l], (size_t)p.n[l] * p.k * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+                DYGNN_HIP(hipMemcpyAsync(F32(p.dt[l]), levels->nbr_dt[l], (size_t)p.n[l] * p.k * sizeof(float), hipMemcpyDeviceToDevice, s));
+            }
+        }
+    } else {
     // level L = [src ; dst]
     hipLaunchKernelGGL(k_cast_ids, dim3((unsigned)ceil_div(2 * batch, 256)), dim3(256), 0, s, src, dst, times, batch, I32(p.ids[p.L]), F64(p.times[p.L]));
     DYGNN_LAUNCH_CHECK();
@@ -612,6 +624,7 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
         hipLaunchKernelGGL(k_tgat_expand, dim3((unsigned)ceil_div(p.n[l], 4)), dim3(256), 0, s, csr->indptr, csr->nbr, csr->eid, csr->ts, csr->num_nodes,
                            I32(p.ids[l]), F64(p.times[l]), p.n[l], p.k, I32(p.ids[l - 1]), F64(p.times[l - 1]), I32(p.eid[l]), F32(p.dt[l]));
         DYGNN_LAUNCH_CHECK();
+    }
     }
     // bottom-up: layer l turns level-(l-1) embeddings (raw features for l = 1) into level-l embeddings
     const float scale = (float)pow((double)p.hd, -0.5);
@@ -759,6 +772,13 @@ static TgnPlan make_tgn_plan(const dygnn_tgat_config& c, int64_t N, int64_t B) {
     return p;
 }
 }  // namespace dygnn
+
+extern "C" int dygnn_tgat_forward_levels(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_tgat_levels* levels, const float* node_feat,
+                                         const float* edge_feat, int64_t batch, float* out_src, float* out_dst, void* workspace, size_t workspace_bytes,
+                                         dygnn_stream_t stream) {
+    DYGNN_REQUIRE(levels != nullptr, "tgat_forward_levels: levels is NULL");
+    return tgat_forward_impl(cfg, w, nullptr, node_feat, edge_feat, nullptr, nullptr, nullptr, batch, out_src, out_dst, workspace, workspace_bytes, stream, levels);
+}
 
 extern "C" int dygnn_tgat_forward(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_csr* csr, const float* node_feat,
                                   const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t batch,

@@ -69,7 +69,8 @@ class TGAT(nn.Module):
         """models/TGAT.py:48-64: two float32 tensors [B, node_feat_dim] on the model's device."""
         if self.training and torch.is_grad_enabled():
             raise NotImplementedError("training-mode forward / backward through the HIP path is not built yet (SURVEY.md §8f-1)")
-        self.neighbor_sampler._require_recent()
+        random_strategy = self.neighbor_sampler.sample_neighbor_strategy != "recent"
+        self.neighbor_sampler._check_strategy()
         dev = self.merge_layers[0].fc1.weight.device
         if dev.type != "cuda":
             raise _capi.DygnnError("dyglib_amd.TGAT runs on an MI355X only; there is no CPU fallback")
@@ -103,8 +104,64 @@ class TGAT(nn.Module):
             if len(self._workspace) > 8:
                 self._workspace.clear()
             ws = self._workspace[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if random_strategy:
+            lv, keep = self._sample_levels_host(src.cpu().numpy(), dst.cpu().numpy(), tms.cpu().numpy(), int(num_neighbors), dev)
+            _capi.check(self._lib.dygnn_tgat_forward_levels(C.byref(cfg), C.byref(w), C.byref(lv), self.node_raw_features.data_ptr(),
+                                                            self.edge_raw_features.data_ptr(), B, out_src.data_ptr(), out_dst.data_ptr(),
+                                                            ws.data_ptr(), ws.numel(), _capi.current_stream_ptr()))
+            torch.cuda.current_stream(dev).synchronize()          # `keep` (the level tensors) may be freed afterwards
+            return out_src, out_dst
         _capi.check(self._lib.dygnn_tgat_forward(C.byref(cfg), C.byref(w), self.neighbor_sampler.csr.on_device(dev),
                                                  self.node_raw_features.data_ptr(), self.edge_raw_features.data_ptr(),
                                                  src.data_ptr(), dst.data_ptr(), tms.data_ptr(), B, out_src.data_ptr(), out_dst.data_ptr(),
                                                  ws.data_ptr(), ws.numel(), _capi.current_stream_ptr()))
         return out_src, out_dst
+
+    # ---- random sampling strategies: the draws are replayed on the host in the reference's recursion order ----------------
+    def _sample_levels_host(self, src: np.ndarray, dst: np.ndarray, t: np.ndarray, k: int, dev):
+        """Level sets for dygnn_tgat_forward_levels.  models/TGAT.py:92-110: compute_node_temporal_embeddings(nodes, l) first
+        recurses for the nodes themselves at layer l-1 (drawing THEIR neighbours), then draws the layer-l neighbours, then
+        recurses for those; src is processed completely before dst (models/TGAT.py:57-62).  With a random sampler every one of
+        those draws is independent and must consume the RandomState in exactly that order."""
+        if self.num_layers not in (1, 2):
+            raise NotImplementedError("TGAT with a random sampling strategy is built for num_layers 1 and 2")
+        smp = self.neighbor_sampler
+        L = self.num_layers
+
+        def draw(nodes, times):
+            n, e, tn = smp.get_historical_neighbors(nodes, times, num_neighbors=k)            # host round trip, RandomState replay
+            dt = (times[:, None] - tn).astype(np.float32)                                     # models/TGAT.py:116-119
+            return n, e, tn, dt
+
+        per_side = []
+        for nodes in (src, dst):
+            if L == 1:
+                per_side.append({"top": draw(nodes, t)})
+            else:
+                d1 = draw(nodes, t)                                        # neighbours of the nodes themselves, for their layer-1 embedding
+                d2 = draw(nodes, t)                                        # layer-2 neighbours
+                d3 = draw(d2[0].reshape(-1), d2[2].reshape(-1).astype(np.float64))           # neighbours of those, for THEIR layer-1 embedding
+                per_side.append({"self": d1, "top": d2, "nbr": d3})
+        s_, d_ = per_side
+        ids = {L: np.concatenate([src, dst])}
+        eid, dts = {}, {}
+        eid[L] = np.concatenate([s_["top"][1], d_["top"][1]])
+        dts[L] = np.concatenate([s_["top"][3], d_["top"][3]])
+        ids[L - 1] = np.concatenate([ids[L], s_["top"][0].reshape(-1), d_["top"][0].reshape(-1)])
+        if L == 2:
+            eid[1] = np.concatenate([s_["self"][1], d_["self"][1], s_["nbr"][1], d_["nbr"][1]])
+            dts[1] = np.concatenate([s_["self"][3], d_["self"][3], s_["nbr"][3], d_["nbr"][3]])
+            nb1 = np.concatenate([s_["self"][0], d_["self"][0], s_["nbr"][0], d_["nbr"][0]])
+            ids[0] = np.concatenate([ids[1], nb1.reshape(-1)])
+        lv = _capi.TgatLevels()
+        keep = []
+        for l in range(L + 1):
+            a = torch.from_numpy(np.ascontiguousarray(ids[l], dtype=np.int32)).to(dev)
+            keep.append(a)
+            lv.ids[l] = a.data_ptr()
+            if l >= 1:
+                b = torch.from_numpy(np.ascontiguousarray(eid[l], dtype=np.int32)).to(dev)
+                c = torch.from_numpy(np.ascontiguousarray(dts[l], dtype=np.float32)).to(dev)
+                keep += [b, c]
+                lv.nbr_eid[l], lv.nbr_dt[l] = b.data_ptr(), c.data_ptr()
+        return lv, keep

@@ -211,6 +211,21 @@ int dygnn_tgat_forward(const dygnn_tgat_config* cfg_host, const dygnn_tgat_weigh
                        const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
                        float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
 
+/* The same forward on PRE-SAMPLED neighbours, for the random strategies (uniform / time_interval_aware, e.g. the reference's
+ * best TGAT configuration on Reddit, utils/load_configs.py:83-84): the draws must come from the sampler's numpy RandomState
+ * in the reference's recursion order (models/TGAT.py:92-110), so the host builds the level sets and this entry point runs
+ * everything else.  Level L = the 2*batch query nodes [src ; dst]; level l-1 = [level-l entries ; their k sampled neighbours
+ * (row-major)].  For l = 1..L: nbr_eid[l] / nbr_dt[l] are [n_l, k] (edge id; float32(t_entry - float32(t_neighbour)),
+ * models/TGAT.py:116-119); ids[l] for l = 0..L are the node ids of the level entries (int32).  All device pointers. */
+typedef struct dygnn_tgat_levels {
+    const int32_t* ids[DYGNN_MAX_LAYERS + 1];
+    const int32_t* nbr_eid[DYGNN_MAX_LAYERS + 1];          /* [0] unused */
+    const float* nbr_dt[DYGNN_MAX_LAYERS + 1];             /* [0] unused */
+} dygnn_tgat_levels;
+int dygnn_tgat_forward_levels(const dygnn_tgat_config* cfg_host, const dygnn_tgat_weights* w_host, const dygnn_tgat_levels* levels_host,
+                              const float* node_feat, const float* edge_feat, int64_t batch,
+                              float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * TGN: MemoryModel.compute_src_dst_node_temporal_embeddings with model_name == 'TGN'
  * (models/MemoryModel.py:87-168): GRU memory update from the last pending raw message of every node

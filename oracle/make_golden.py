@@ -179,6 +179,24 @@ def run_tgat_case(name: str) -> dict:
             "torch_version": np.array(torch.__version__)}
 
 
+def run_tgat_random_case(name: str) -> dict:
+    c = gc.build_tgat_case(name)
+    d, cfg = c["data"], c["tgat_cfg"]
+    ref_data = RefData(d.src_node_ids, d.dst_node_ids, d.node_interact_times, d.edge_ids, d.labels)
+    out = {}
+    for tag, (strategy, seed, tsf) in gc.SAMPLING_STRATEGIES.items():
+        sampler = ref_get_neighbor_sampler(ref_data, sample_neighbor_strategy=strategy, time_scaling_factor=tsf, seed=seed)
+        model = RefTGAT(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"], num_layers=cfg["num_layers"],
+                        num_heads=cfg["num_heads"], dropout=0.1, device="cpu")
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in c["tgat_params"].items()}, strict=True)
+        model.eval()
+        with torch.no_grad():
+            se, de = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"], num_neighbors=cfg["num_neighbors"])
+            nse, nde = model.compute_src_dst_node_temporal_embeddings(c["src"], c["neg_dst"], c["times"], num_neighbors=cfg["num_neighbors"])
+        out[f"{tag}_src_emb"], out[f"{tag}_dst_emb"], out[f"{tag}_neg_src_emb"], out[f"{tag}_neg_dst_emb"] = se.numpy(), de.numpy(), nse.numpy(), nde.numpy()
+    return out
+
+
 def run_tgn_case(name: str) -> dict:
     c = gc.build_tgn_case(name)
     d, cfg = c["data"], c["tgn_cfg"]
@@ -212,8 +230,13 @@ def run_tgn_case(name: str) -> dict:
 def main():
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(8)
-    names = sys.argv[1:] or (list(gc.CASES) + list(gc.TGAT_CASES) + list(gc.TGN_CASES) + ["sampling_" + n for n in gc.SAMPLING_CASES] + ["loader_toy"] + ["grads_" + n for n in gc.GRAD_CASES])
+    names = sys.argv[1:] or (list(gc.CASES) + list(gc.TGAT_CASES) + list(gc.TGN_CASES) + ["sampling_" + n for n in gc.SAMPLING_CASES] + ["loader_toy"] + ["grads_" + n for n in gc.GRAD_CASES] + ["tgat_rand_" + n for n in gc.TGAT_RANDOM_CASES])
     for name in names:
+        if name.startswith("tgat_rand_"):
+            path = os.path.join(gc.GOLDEN_DIR, name + ".npz")
+            np.savez_compressed(path, **run_tgat_random_case(name[len("tgat_rand_"):]))
+            print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+            continue
         if name.startswith("grads_"):
             path = os.path.join(gc.GOLDEN_DIR, name + ".npz")
             np.savez_compressed(path, **run_grad_case(name[len("grads_"):]))

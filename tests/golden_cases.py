@@ -44,6 +44,11 @@ TGAT_CASES = {
     "tgat_hub_l1_k10": dict(graph="hub_p4_l48", num_layers=1, num_neighbors=10, param_seed=203),
 }
 
+# TGAT with the random sampling strategies (the reference's best TGAT configuration on Reddit is `uniform`, utils/load_configs.py:83-84):
+# fixtures tgat_rand_<case>.npz hold, per strategy tag of SAMPLING_STRATEGIES (defined below), the embeddings of the positive call followed by
+# the negative call on ONE sampler (the RandomState carries over).
+TGAT_RANDOM_CASES = ("tgat_bip_l2_k20", "tgat_hub_l1_k10")
+
 # TGN (BASELINE config 5): a chronological run of batches from interaction 0; per batch the negative call then the
 # positive call (evaluate_models_utils.py:93-113).  (graph case, layers, k, param seed, batch size, number of batches)
 TGN_CASES = {
