@@ -113,8 +113,9 @@ constexpr int kKvNT = 17;            // column tiles per workgroup (Dq <= 272)
 constexpr int kKvSlots = 8;          // ring depth in k-chunks
 constexpr int kKvLds = kKvSlots * kKvNT * 1024;
 
+__device__ __attribute__((noinline)) float cos_libm(float x) { return cosf(x); }
 __device__ __forceinline__ float cos_time_t(float x) {      // same range reduction + polynomial as dygformer_fused3.hip
-    if (!(fabsf(x) <= 3.0e7f)) return cosf(x);
+    if (!(fabsf(x) <= 3.0e7f)) return cos_libm(x);
     const float INV_HI = 0.15915493667125702f, INV_LO = 6.4206382432985265e-09f;
     const float p = x * INV_HI;
     const float e = fmaf(x, INV_HI, -p);
@@ -408,12 +409,81 @@ __global__ __launch_bounds__(256) void k_tgat_attn_lin(const float* __restrict__
     auto dot4 = [](const f4 a, const f4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); };
     const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
     f4 xs[KCACHE > 0 ? KCACHE : 1][2];
+    if (KCACHE > 0) {
+        // all k rows are requested back to back (one memory latency for the whole neighbourhood), then every (row, head)
+        // score is reduced: 2*k independent butterfly chains that pipeline instead of one chain per loop iteration
+        // Branch-free gathers: which table a lane reads (node / edge / none) depends only on its column, so every lane
+        // issues exactly one unconditional float4 load per row and pass (lanes of the time columns and beyond read row 0 of
+        // the edge table and discard it); the row indices are wave-uniform scalars.  The cosines are filled in afterwards.
+        const float* ntab = h_lower ? h_lower : node_feat;
+        const float* bp[2]; size_t st[2]; int cls[2];
 #pragma unroll
-    for (int j = 0; j < (KCACHE > 0 ? KCACHE : 1 << 30); ++j) {
+        for (int ps = 0; ps < 2; ++ps) {
+            const int kk = 4 * (lane + 64 * ps);
+            cls[ps] = kk < Fn ? 0 : kk < Fn + Fe ? 1 : kk < Dkv ? 2 : 3;
+            bp[ps] = cls[ps] == 0 ? ntab + kk : cls[ps] == 1 ? edge_feat + (kk - Fn) : edge_feat;
+            st[ps] = cls[ps] == 0 ? (size_t)Fn : cls[ps] == 1 ? (size_t)Fe : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < KCACHE; ++j) {
+            const int64_t r = i * k + (j < k ? j : 0);
+            const int64_t nrow = h_lower ? n + r : (int64_t)lower_ids[n + r];
+            const int64_t erow = nbr_eid[r];
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) xs[j][ps] = *reinterpret_cast<const f4*>(bp[ps] + (cls[ps] == 0 ? nrow : erow) * st[ps]);
+        }
+        // time encoding: computed in a ROLLED loop into LDS (the cosine code exists once; unrolled over 20 rows it alone was
+        // 100 KB of straight-line code, more than the instruction cache, executed once per wave), then read back per row
+        float* tf = reinterpret_cast<float*>(smem) + 4 * H * k + (size_t)wave * KCACHE * Ft;          // [KCACHE][Ft]
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            if (cls[ps] == 2) {
+                const int f = 4 * (lane + 64 * ps) - Fn - Fe;
+                const f4 w = *reinterpret_cast<const f4*>(tw + f), b = *reinterpret_cast<const f4*>(tb + f);
+#pragma unroll 1
+                for (int j = 0; j < k; ++j) {
+                    const float dt = nbr_dt[i * k + j];
+                    *reinterpret_cast<f4*>(tf + j * Ft + f) = f4{cos_time_t(fmaf(dt, w.x, b.x)), cos_time_t(fmaf(dt, w.y, b.y)), cos_time_t(fmaf(dt, w.z, b.z)),
+                                                                cos_time_t(fmaf(dt, w.w, b.w))};
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            if (cls[ps] == 2) {
+                const int f = 4 * (lane + 64 * ps) - Fn - Fe;
+#pragma unroll
+                for (int j = 0; j < KCACHE; ++j) xs[j][ps] = *reinterpret_cast<const f4*>(tf + (j < k ? j : 0) * Ft + f);
+            } else if (cls[ps] == 3) {
+#pragma unroll
+                for (int j = 0; j < KCACHE; ++j) xs[j][ps] = zero;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KCACHE; ++j)
+            if (j >= k) { xs[j][0] = zero; xs[j][1] = zero; }
+        for (int h = 0; h < H; ++h) {
+            const f4* qh = reinterpret_cast<const f4*>(qk + ((size_t)i * H + h) * Dkv);
+            const f4 qa = v0 ? qh[x0] : zero, qb = v1 ? qh[x1] : zero;
+            float sc[KCACHE > 0 ? KCACHE : 1];
+#pragma unroll
+            for (int j = 0; j < KCACHE; ++j) sc[j] = dot4(qa, xs[j][0]) + dot4(qb, xs[j][1]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                for (int j = 0; j < KCACHE; ++j) sc[j] += __shfl_xor(sc[j], o, 64);
+#pragma unroll
+            for (int j = 0; j < KCACHE; ++j)
+                if (lane == j && j < k) pw[h * k + j] = lower_ids[n + i * k + j] == 0 ? -1e10f : sc[j] * scale;      // modules.py:173, :176-184
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < (KCACHE > 0 ? 0 : 1 << 30); ++j) {
         if (j >= k) break;
         const int64_t r = i * k + j;
         const f4 xa = v0 ? fetch(r, x0) : zero, xb = v1 ? fetch(r, x1) : zero;
-        if (KCACHE > 0) { xs[j][0] = xa; xs[j][1] = xb; }
         for (int h = 0; h < H; ++h) {
             const f4* qh = reinterpret_cast<const f4*>(qk + ((size_t)i * H + h) * Dkv);
             float sc = (v0 ? dot4(qh[x0], xa) : 0.f) + (v1 ? dot4(qh[x1], xb) : 0.f);
@@ -643,7 +713,7 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
             const dim3 grid((unsigned)ceil_div(n, 4));
             const size_t lds = (size_t)4 * p.H * p.k * sizeof(float);
             if (p.k <= 20)
-                hipLaunchKernelGGL((k_tgat_attn_lin<20>), grid, dim3(256), lds, s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]), F32(p.dt[l]),
+                hipLaunchKernelGGL((k_tgat_attn_lin<20>), grid, dim3(256), lds + (size_t)4 * 20 * p.Ft * sizeof(float), s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]), F32(p.dt[l]),
                                    w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z));
             else
                 hipLaunchKernelGGL((k_tgat_attn_lin<0>), grid, dim3(256), lds, s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]), F32(p.dt[l]),
