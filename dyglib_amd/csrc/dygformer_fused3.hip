@@ -129,6 +129,7 @@ struct Args {
     int proj_frags;               // total projection fragments
     int slab_chunks;              // k-chunks (steps) per LDS slab
     int scr_floats;               // LDS floats reserved for the window arrays (the slab follows)
+    int slab_in_ring;             // long windows (e.g. L = 2048): the slab borrows the weight ring, whose stream then opens after the prologue
     const float* bias_x;          // [208] projection biases in model-dim order
     const float* outfrag;         // output layer as fragments [ceil(Fn/16) tiles][13 k-chunks]
     LayerP layer[DYGNN_MAX_LAYERS];
@@ -307,9 +308,9 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
     // ---- weights start moving at once: the first four stages of the layer stream into the ring, the first slab of
     // projection fragments into the K/V region behind the window arrays (all of it lands during the window phase)
     WStream ws;
-    ws.open(a.stream, lds + kLdsRing, lane, wave, a.nstages);
+    if (!a.slab_in_ring) ws.open(a.stream, lds + kLdsRing, lane, wave, a.nstages);
     const float* ringl = lds + kLdsRing + lane * 4;
-    float* slab = lds + a.scr_floats;
+    float* slab = a.slab_in_ring ? lds + kLdsRing : lds + a.scr_floats;
     const float* slabl = slab + lane * 4;
     const int slab_frags = 4 * a.slab_chunks;
     auto load_slab = [&](int k) {
@@ -550,7 +551,13 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
         TACC(T_MISC);
         float* b1s = misc + kMiscB1 + (l & 1) * kHid;
         for (int i = tid; i < kHid; i += 512) b1s[i] = W.b1[i];
-        if (l == 0) __syncthreads();     // the re-zeroing of K/V above is complete before the first K/V rows are written
+        if (l == 0) {
+            if (a.slab_in_ring) {        // the ring was the projection slab until now: start the layer stream (one exposed DMA latency)
+                ws.open(a.stream, lds + kLdsRing, lane, wave, a.nstages);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();             // the re-zeroing of K/V above is complete before the first K/V rows are written
+        }
 
         f4 xn[kNT];
         ws.fit(2);                       // LN0 gamma, beta: two vector fragments
@@ -944,6 +951,7 @@ struct PackLayout3 {       // float offsets relative to PackedLayout.fused3
     size_t aux; int64_t naux;                      // output-layer fragments
     size_t proj; int64_t nproj;                    // projection fragments
     int scr_floats, slab_chunks;                   // LDS split of the K/V region during the prologue
+    int np, slab_in_ring;                          // pairs per workgroup (0: shape unsupported); slab placed in the weight ring
     size_t desc;           // FragDesc table (device copy), 8-byte aligned
     size_t total;
 };
@@ -978,9 +986,16 @@ static PackLayout3 make_layout3(const Dims& d) {
     for (int ch = 0; ch < 4; ++ch) f.nproj += 4 * (int64_t)((K[ch] + 15) / 16);
     f.proj = take((size_t)f.nproj * kFrag);
     f.desc = take(((size_t)(f.nfrag + f.naux + f.nproj) * sizeof(FragDesc) + 3) / 4);
-    const int np = d.Tmax <= 64 ? 2 : 1;
-    f.scr_floats = np * 5 * 2 * ((d.Smax + 3) & ~3);
-    f.slab_chunks = (kScratchFloats - f.scr_floats) / (4 * kFrag);
+    // prologue LDS split: pairs per workgroup, window arrays (5 x 2 sides x Smax ints per pair), projection slab
+    const int per_pair = 5 * 2 * ((d.Smax + 3) & ~3);
+    f.np = 0; f.slab_in_ring = 0; f.scr_floats = 0; f.slab_chunks = 0;
+    if (d.Tmax <= 64 && 2 * per_pair + 8 * 4 * kFrag <= kScratchFloats) f.np = 2;
+    else if (d.Tmax <= 128 && per_pair + 8 * 4 * kFrag <= kScratchFloats) f.np = 1;
+    else if (d.Tmax <= 128 && per_pair <= kScratchFloats) { f.np = 1; f.slab_in_ring = 1; }
+    if (f.np) {
+        f.scr_floats = f.np * per_pair;
+        f.slab_chunks = f.slab_in_ring ? kRing / 4 : (kScratchFloats - f.scr_floats) / (4 * kFrag);
+    }
     f.total = o;
     return f;
 }
@@ -988,10 +1003,10 @@ static PackLayout3 make_layout3(const Dims& d) {
 bool supported(const Dims& d) {
     if (!(d.C == kC && d.H == 2 && d.Fn % 4 == 0 && d.Fe % 4 == 0 && d.Ft % 4 == 0 && d.Fn >= 16 && d.Fe >= 16 && d.Ft >= 16 &&
           d.Fn <= 512 && d.NL <= DYGNN_MAX_LAYERS && d.Tmax <= 128 && (kLdsMisc + kMiscFloats + 2 * d.Ft) * 4 <= kLdsBytes)) return false;
-    const int np = d.Tmax <= 64 ? 2 : 1;
-    // window arrays: 5 x (2 sides, each padded to a multiple of 4) ints per pair in the K/V region; k/50 multiply-shift range
-    // ... and behind them at least 8 k-chunks of projection fragments
-    return (size_t)np * 5 * (2 * (size_t)((d.Smax + 3) & ~3)) + 8 * 4 * kFrag <= (size_t)kScratchFloats && d.P * kC < 12000;
+    // k/50 multiply-shift range; the window arrays must fit the K/V region (make_layout3 decides how)
+    if (!(d.P * kC < 12000)) return false;
+    const int per_pair = 5 * 2 * ((d.Smax + 3) & ~3);
+    return per_pair <= kScratchFloats;
 }
 
 size_t packed_floats(const Dims& d) { return supported(d) ? make_layout3(d).total : 0; }
@@ -1069,6 +1084,7 @@ int forward_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_
     }
     a.outfrag = base + f.aux;
     a.projw = base + f.proj; a.proj_frags = (int)f.nproj; a.slab_chunks = f.slab_chunks; a.scr_floats = f.scr_floats;
+    a.slab_in_ring = f.slab_in_ring;
     a.outT = packed + pl.outputT; a.outb = w->output_b;
     a.out_src = out_src; a.out_dst = out_dst;
     a.tap_enc = taps ? taps->encoder_input : nullptr;
@@ -1084,7 +1100,7 @@ int forward_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_
         DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         attr_set = true;
     }
-    if (d.Tmax <= 64) hipLaunchKernelGGL(k_dygformer_fused3<4>, dim3((unsigned)((B + 1) / 2)), dim3(512), kLdsBytes, s, a);
+    if (f.np == 2) hipLaunchKernelGGL(k_dygformer_fused3<4>, dim3((unsigned)((B + 1) / 2)), dim3(512), kLdsBytes, s, a);
     else hipLaunchKernelGGL(k_dygformer_fused3<8>, dim3((unsigned)B), dim3(512), kLdsBytes, s, a);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;

@@ -459,7 +459,7 @@ int forward_generic(const Dims& d, const PackedLayout& pl, const dygnn_dygformer
     int fmax = d.Fn > d.Fe ? d.Fn : d.Fe; fmax = fmax > d.Ft ? fmax : d.Ft; fmax = fmax > d.C ? fmax : d.C;
     ea.stage_floats = d.P * fmax;
     const size_t embed_lds = (size_t)2 * d.Smax * 5 * 4 + (size_t)4 * ea.stage_floats * 4;
-    DYGNN_REQUIRE(embed_lds <= 160 * 1024, "embed: LDS request %zu exceeds 160 KiB", embed_lds);
+    if (embed_lds > 160 * 1024) { set_error("generic path: window arrays + patch staging need %zu bytes of LDS (> 160 KiB)", embed_lds); return DYGNN_E_UNSUPPORTED; }
     DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_embed), hipFuncAttributeMaxDynamicSharedMemorySize, (int)embed_lds));
     hipLaunchKernelGGL(k_embed, dim3((unsigned)B), dim3(256), embed_lds, s, ea);
     DYGNN_LAUNCH_CHECK();
@@ -473,7 +473,7 @@ int forward_generic(const Dims& d, const PackedLayout& pl, const dygnn_dygformer
     if (taps && taps->encoder_input) DYGNN_HIP(hipMemcpyAsync(taps->encoder_input, X, act_bytes, hipMemcpyDeviceToDevice, s));
 
     const size_t att_lds = ((size_t)d.Tmax * (d.hd + 1) + (size_t)d.Tmax * d.hd + 4 * d.Tmax) * sizeof(float);
-    DYGNN_REQUIRE(att_lds <= 160 * 1024, "attention: LDS request %zu exceeds 160 KiB", att_lds);
+    if (att_lds > 160 * 1024) { set_error("generic path: attention needs %zu bytes of LDS (> 160 KiB)", att_lds); return DYGNN_E_UNSUPPORTED; }
     DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention), hipFuncAttributeMaxDynamicSharedMemorySize, (int)att_lds));
 
     for (int l = 0; l < d.NL; ++l) {

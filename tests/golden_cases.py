@@ -35,6 +35,10 @@ CASES = {
     # BASELINE config-4 shape: P=8 / L=512 -> 128 tokens per pair.
     "bip_p8_l512": dict(kind="bipartite", users=6, items=4, edges=4000, graph_seed=15, dup_every=0,
                         patch_size=8, max_len=512, param_seed=105, batch="tail6", neg_seed=9),
+    # the reference's best configuration for CanParl (utils/load_configs.py:219-221): P=64 / L=2048, 64 tokens over 4096 positions
+    # (windows truncated to 2047 neighbours: node degrees are 2250 .. 3000 here).
+    "bip_p64_l2048": dict(kind="bipartite", users=3, items=2, edges=9000, graph_seed=16, dup_every=0,
+                          patch_size=64, max_len=2048, param_seed=106, batch="tail6", neg_seed=10),
 }
 
 # TGAT (BASELINE config 3) recipes reuse the graphs above: (graph case, num_layers, num_neighbors, param seed)
