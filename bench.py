@@ -280,6 +280,8 @@ def main():
         "mean_auc": round(float(acc[0] / max(acc[2], 1)), 4),
     }
 
+    if rank == 0 and world == 1:
+        out["stages"] = sampler_stage(sampler, data, dev)           # stage-level number for the neighbour lookup
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(params, mparams, node_feat, edge_feat, data, batches, L, P, args.cpu_seconds)
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
@@ -287,6 +289,31 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def sampler_stage(sampler, data, dev, n_queries: int = 400_000, k: int = 20, reps: int = 5) -> dict:
+    """get_historical_neighbors ('recent', k = 20) on random (endpoint, time) queries of the evaluation span: queries/s and the
+    algorithmic-byte rate of DESIGN.md §4.1 against the 8 TB/s HBM peak (the reference: 149 k queries/s on the CPU)."""
+    E = data.num_interactions
+    rs = np.random.RandomState(1)
+    idx = rs.randint(int(0.7 * E), E, size=n_queries // 2)
+    nodes_h = np.concatenate([data.src_node_ids[idx], data.dst_node_ids[idx]])
+    times_h = np.concatenate([data.node_interact_times[idx], data.node_interact_times[idx]])
+    nodes, times = torch.from_numpy(nodes_h).to(dev), torch.from_numpy(times_h).to(dev)
+    sampler.get_historical_neighbors_device(nodes, times, k)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        sampler.get_historical_neighbors_device(nodes, times, k)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    deg = (sampler.csr.indptr[nodes_h + 1] - sampler.csr.indptr[nodes_h]).astype(np.float64)
+    probes = np.maximum(1, np.ceil(np.log(deg + 1) / np.log(64)))
+    algo = float((8 * 64 * probes).sum() + 16 * np.minimum(deg, k).sum() + 20.0 * k * len(nodes_h) + 16 * len(nodes_h))
+    return {"sampler_recent_k20_queries_per_s": round(len(nodes_h) / sec), "sampler_algorithmic_GBps": round(algo / sec / 1e9, 1),
+            "sampler_frac_of_hbm_peak": round(algo / sec / 8.0e12, 4), "queries": len(nodes_h)}
 
 
 def cpu_baseline(params, mparams, node_feat, edge_feat, data, batches, L, P, budget_s):
