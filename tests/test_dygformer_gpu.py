@@ -173,3 +173,27 @@ def test_many_calls_in_one_launch_match_separate_calls():
                 lens.append(tuple(taps["seq_lens"].cpu().tolist()))
                 assert torch.equal(many_s[i], s1) and torch.equal(many_d[i], d1), (impl, i)
         assert len(set(lens)) > 1, lens          # the groups really were padded to different lengths
+
+
+def test_large_timestamps_take_the_libm_cosine_path():
+    """Time differences of ~1e9 s (UNIX-epoch style timestamps): w*dt exceeds the 3e7 rad range of the fast range reduction
+    for the largest frequencies, so those lanes fall back to libm's cosf — results must still match the oracle."""
+    from dyglib_amd import DyGFormer, get_neighbor_sampler
+    data, nf, ef = syn.make_bipartite_graph(50, 10, 2500, seed=31)
+    data.node_interact_times = np.ascontiguousarray(data.node_interact_times * 1000.0)      # up to 2.7e9
+    params = syn.make_dygformer_params(9, patch_size=2)
+    sampler = get_neighbor_sampler(data, "recent", seed=1, device="cuda:0")
+    model = DyGFormer(nf, ef, sampler, 100, 50, patch_size=2, num_layers=2, num_heads=2, dropout=0.1,
+                      max_input_sequence_length=64, device="cuda:0")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    model = model.to("cuda:0").eval()
+    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    idx = np.arange(data.num_interactions - 40, data.num_interactions)
+    src, dst, t = data.src_node_ids[idx], data.dst_node_ids[idx], data.node_interact_times[idx]
+    with torch.no_grad():
+        os_, od = orc.dygformer_forward(params, nf, ef, adj, src, dst, t, 2, 64)
+        for impl in (1, 2, 3):
+            model.impl = impl
+            gs, gd = model.compute_src_dst_node_temporal_embeddings(src, dst, t)
+            close(gs.cpu().numpy(), os_.numpy(), f"large t, impl {impl} src")
+            close(gd.cpu().numpy(), od.numpy(), f"large t, impl {impl} dst")
