@@ -153,24 +153,32 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
         }
     };
     auto stash = [&](int buf) {                   // registers -> LDS tile `buf` (k-major)
+        // LDS column of element (k, m) = (m + 16 * (k / 4)) mod BM: the four k-groups a wave writes at once (rows k, k+4, k+8,
+        // k+12 of the same m) would otherwise share their banks (row stride = 16 mod 64 -> 4 rows = 0 mod 64): 4-way conflicts
         if (p.transA) {
 #pragma unroll
-            for (int e = 0; e < NA; ++e) *reinterpret_cast<f4*>(&As[buf][(tid / (BM / 4)) + (1024 / BM) * e][(tid % (BM / 4)) * 4]) = ra[e];
+            for (int e = 0; e < NA; ++e) {
+                const int k = (tid / (BM / 4)) + (1024 / BM) * e, m = (tid % (BM / 4)) * 4;
+                *reinterpret_cast<f4*>(&As[buf][k][(m + 16 * (k >> 2)) & (BM - 1)]) = ra[e];
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < NA; ++e) {
-                const int m = (tid >> 2) + 64 * e, k = (tid & 3) * 4;
-                As[buf][k][m] = ra[e].x; As[buf][k + 1][m] = ra[e].y; As[buf][k + 2][m] = ra[e].z; As[buf][k + 3][m] = ra[e].w;
+                const int m = (tid >> 2) + 64 * e, k = (tid & 3) * 4, mr = (m + 16 * (k >> 2)) & (BM - 1);
+                As[buf][k][mr] = ra[e].x; As[buf][k + 1][mr] = ra[e].y; As[buf][k + 2][mr] = ra[e].z; As[buf][k + 3][mr] = ra[e].w;
             }
         }
         if (!p.transB) {
 #pragma unroll
-            for (int e = 0; e < NB; ++e) *reinterpret_cast<f4*>(&Bs[buf][(tid / (BN / 4)) + (1024 / BN) * e][(tid % (BN / 4)) * 4]) = rb[e];
+            for (int e = 0; e < NB; ++e) {
+                const int k = (tid / (BN / 4)) + (1024 / BN) * e, n = (tid % (BN / 4)) * 4;
+                *reinterpret_cast<f4*>(&Bs[buf][k][(n + 16 * (k >> 2)) & (BN - 1)]) = rb[e];
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < NB; ++e) {
-                const int n = (tid >> 2) + 64 * e, k = (tid & 3) * 4;
-                Bs[buf][k][n] = rb[e].x; Bs[buf][k + 1][n] = rb[e].y; Bs[buf][k + 2][n] = rb[e].z; Bs[buf][k + 3][n] = rb[e].w;
+                const int n = (tid >> 2) + 64 * e, k = (tid & 3) * 4, nr = (n + 16 * (k >> 2)) & (BN - 1);
+                Bs[buf][k][nr] = rb[e].x; Bs[buf][k + 1][nr] = rb[e].y; Bs[buf][k + 2][nr] = rb[e].z; Bs[buf][k + 3][nr] = rb[e].w;
             }
         }
     };
@@ -185,9 +193,9 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
         for (int kk = 0; kk < 4; ++kk) {
             float a[WM], b[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = As[buf][4 * kk + g][16 * WM * wy + 16 * i + c];
+            for (int i = 0; i < WM; ++i) a[i] = As[buf][4 * kk + g][(16 * WM * wy + 16 * i + c + 16 * kk) & (BM - 1)];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = Bs[buf][4 * kk + g][16 * WN * wx + 16 * j + c];
+            for (int j = 0; j < WN; ++j) b[j] = Bs[buf][4 * kk + g][(16 * WN * wx + 16 * j + c + 16 * kk) & (BN - 1)];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
