@@ -320,33 +320,50 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ X, con
     for (int k = lane; k < D; k += 64) Y[row * D + k] = (x[k] - mean) * rstd * gamma[k] + beta[k];
     if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 }
-// dX[row] += LN'(dY) ; dgamma += sum dY*xhat ; dbeta += sum dY   (per-workgroup partial sums, then atomics)
+// dX[row] += LN'(dY) ; dgamma += sum dY*xhat ; dbeta += sum dY.  A lane owns columns lane, lane+64, ...: its partial sums over the
+// 16 rows of its wave stay in registers, the four waves meet in LDS, one global atomic per column and workgroup.  D <= 256.
 __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean_i,
                                                   const float* __restrict__ rstd_i, const float* __restrict__ gamma, int64_t M, int D,
                                                   float* __restrict__ dX, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    extern __shared__ float part[];            // [2][D]
-    for (int k = threadIdx.x; k < 2 * D; k += 256) part[k] = 0.f;
-    __syncthreads();
+    extern __shared__ float part[];            // [4 waves][2][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
     for (int rr = 0; rr < 16; ++rr) {          // 64 rows per workgroup
         const int64_t row = (int64_t)blockIdx.x * 64 + rr * 4 + wave;
         if (row >= M) break;
         const float mean = mean_i[row], rstd = rstd_i[row];
-        float s1 = 0.f, s2 = 0.f;
-        for (int k = lane; k < D; k += 64) {
-            const float xh = (X[row * D + k] - mean) * rstd, gy = dY[row * D + k] * gamma[k];
-            s1 += gy; s2 = fmaf(gy, xh, s2);
+        float xh[4], dy[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = lane + 64 * q;
+            xh[q] = 0.f; dy[q] = 0.f;
+            if (k < D) {
+                xh[q] = (X[row * D + k] - mean) * rstd; dy[q] = dY[row * D + k];
+                const float gy = dy[q] * gamma[k];
+                s1 += gy; s2 = fmaf(gy, xh[q], s2);
+            }
         }
         s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
-        for (int k = lane; k < D; k += 64) {
-            const float xh = (X[row * D + k] - mean) * rstd, dy = dY[row * D + k];
-            dX[row * D + k] += rstd * (dy * gamma[k] - s1 - xh * s2);
-            atomicAdd(&part[k], dy * xh);
-            atomicAdd(&part[D + k], dy);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = lane + 64 * q;
+            if (k < D) {
+                dX[row * D + k] += rstd * (dy[q] * gamma[k] - s1 - xh[q] * s2);
+                pg[q] = fmaf(dy[q], xh[q], pg[q]); pb[q] += dy[q];
+            }
         }
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = lane + 64 * q;
+        if (k < D) { part[(wave * 2 + 0) * D + k] = pg[q]; part[(wave * 2 + 1) * D + k] = pb[q]; }
+    }
     __syncthreads();
-    for (int k = threadIdx.x; k < D; k += 256) { atomicAdd(&dgamma[k], part[k]); atomicAdd(&dbeta[k], part[D + k]); }
+    for (int k = threadIdx.x; k < 2 * D; k += 256) {
+        const int which = k / D, col = k % D;
+        const float t = (part[(0 * 2 + which) * D + col] + part[(1 * 2 + which) * D + col]) + (part[(2 * 2 + which) * D + col] + part[(3 * 2 + which) * D + col]);
+        atomicAdd(which ? &dbeta[col] : &dgamma[col], t);
+    }
 }
 
 // ---- softmax over the keys of one (pair, head, query) row + dropout on the probabilities ---------------------------
@@ -623,6 +640,7 @@ static Plan make_plan(const Dims& d, int64_t B) {
 
 static int supported(const Dims& d) {
     if (d.C <= 0 || d.H <= 0 || d.D % d.H != 0) { set_error("train: bad dims"); return DYGNN_E_INVALID; }
+    if (d.D > 256) { set_error("train: model dim > 256 not supported"); return DYGNN_E_UNSUPPORTED; }
     if (d.C * kCoocGroups > 256) { set_error("train: channel_embedding_dim > 51 not supported"); return DYGNN_E_UNSUPPORTED; }
     if ((size_t)5 * 2 * d.Smax * 4 > 60 * 1024) { set_error("train: max_input_sequence_length too large for the embedding kernel"); return DYGNN_E_UNSUPPORTED; }
     return DYGNN_OK;
@@ -666,11 +684,17 @@ extern "C" int dygnn_dygformer_train_forward(const dygnn_dygformer_config* cfg, 
     const int64_t B = batch;
     // window lengths -> this call's padded lengths (one host sync: they size every product below)
     if (int rc = window_lengths_device(d, csr, src, dst, times, B, B, ws, p.wl, s)) return rc;
-    CallDims cd;
-    DYGNN_HIP(hipMemcpyAsync(&cd, ws + p.wl.dims, sizeof(CallDims), hipMemcpyDeviceToHost, s));
-    DYGNN_HIP(hipStreamSynchronize(s));
-    seq_lens_host[0] = cd.S_s; seq_lens_host[1] = cd.S_d;
-    const int Ss = cd.S_s, Sd = cd.S_d, Ts = cd.T_s, T = cd.T, S = Ss + Sd;
+    // the padded lengths size every product below.  seq_lens_host = {0, 0}: read them back here (one host synchronisation of this
+    // stream); non-zero: the caller already knows them (e.g. from dygnn_window_lengths on a side stream) and the call stays asynchronous
+    if (seq_lens_host[0] <= 0 || seq_lens_host[1] <= 0) {
+        CallDims cd;
+        DYGNN_HIP(hipMemcpyAsync(&cd, ws + p.wl.dims, sizeof(CallDims), hipMemcpyDeviceToHost, s));
+        DYGNN_HIP(hipStreamSynchronize(s));
+        seq_lens_host[0] = cd.S_s; seq_lens_host[1] = cd.S_d;
+    }
+    const int Ss = seq_lens_host[0], Sd = seq_lens_host[1];
+    DYGNN_REQUIRE(Ss % d.P == 0 && Sd % d.P == 0 && Ss <= d.Smax && Sd <= d.Smax, "train_forward: bad sequence lengths");
+    const int Ts = Ss / d.P, T = (Ss + Sd) / d.P, S = Ss + Sd;
     const int64_t M = B * T;
     const int D = d.D, C = d.C, H = d.H, hd = d.hd;
     const Drop dr = make_drop(dropout_p, seed);
@@ -772,7 +796,7 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
         if (int rc = mm(s, dH, 4 * D, false, Lw.ffn0_weight, D, false, dBf, D, (int)M, D, 4 * D)) return rc;                    // dxn1
         DYGNN_HIP(hipMemsetAsync(G(Lg.norm1_weight), 0, D * sizeof(float), s));
         DYGNN_HIP(hipMemsetAsync(G(Lg.norm1_bias), 0, D * sizeof(float), s));
-        hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)ceil_div(M, 64)), dim3(256), 2 * D * sizeof(float), s, dBf, F32(L.x1), F32(L.m1), F32(L.r1), Lw.norm1_weight, M, D,
+        hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)ceil_div(M, 64)), dim3(256), 8 * D * sizeof(float), s, dBf, F32(L.x1), F32(L.m1), F32(L.r1), Lw.norm1_weight, M, D,
                            dX, G(Lg.norm1_weight), G(Lg.norm1_bias));                                                          // dX is now dX1
         DYGNN_LAUNCH_CHECK();
         // X1 = Xin + drop(Ao), Ao = Oa Wo^T + bo
@@ -799,7 +823,7 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
         if (int rc = mm(s, dQKV, 3 * D, false, Lw.in_proj_weight, D, false, dA, D, (int)M, D, 3 * D)) return rc;                // dxn0
         DYGNN_HIP(hipMemsetAsync(G(Lg.norm0_weight), 0, D * sizeof(float), s));
         DYGNN_HIP(hipMemsetAsync(G(Lg.norm0_bias), 0, D * sizeof(float), s));
-        hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)ceil_div(M, 64)), dim3(256), 2 * D * sizeof(float), s, dA, F32(p.X[l]), F32(L.m0), F32(L.r0), Lw.norm0_weight, M, D,
+        hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)ceil_div(M, 64)), dim3(256), 8 * D * sizeof(float), s, dA, F32(p.X[l]), F32(L.m0), F32(L.r0), Lw.norm0_weight, M, D,
                            dX, G(Lg.norm0_weight), G(Lg.norm0_bias));                                                          // dX is now dX_l
         DYGNN_LAUNCH_CHECK();
     }

@@ -56,7 +56,7 @@ class _TrainFunction(torch.autograd.Function):
     dygnn_dygformer_backward.  The parameters are passed as inputs only so that autograd routes their gradients."""
 
     @staticmethod
-    def forward(ctx, model, src, dst, tms, dropout_p, seed, *params):
+    def forward(ctx, model, src, dst, tms, dropout_p, seed, seq_lens, *params):
         dev = src.device
         B = src.numel()
         lib, cfg = model._lib, model._cfg
@@ -68,6 +68,8 @@ class _TrainFunction(torch.autograd.Function):
         out_src = torch.empty((B, model.node_feat_dim), dtype=torch.float32, device=dev)
         out_dst = torch.empty_like(out_src)
         seq = (C.c_int32 * 2)()
+        if seq_lens is not None:
+            seq[0], seq[1] = int(seq_lens[0]), int(seq_lens[1])
         csr = model.neighbor_sampler.csr.on_device(dev)
         rc = lib.dygnn_dygformer_train_forward(C.byref(cfg), C.byref(weights), csr, model.node_raw_features.data_ptr(),
                                                model.edge_raw_features.data_ptr(), src.data_ptr(), dst.data_ptr(), tms.data_ptr(), B,
@@ -85,7 +87,11 @@ class _TrainFunction(torch.autograd.Function):
         g_src = (g_src if g_src is not None else torch.zeros((ctx.B, model.node_feat_dim), device=dev)).contiguous().float()
         g_dst = (g_dst if g_dst is not None else torch.zeros((ctx.B, model.node_feat_dim), device=dev)).contiguous().float()
         params = list(model.parameters())
-        grads = [torch.zeros_like(p) for p in params]
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)       # one fill for all gradient buffers
+        grads, o = [], 0
+        for p in params:
+            grads.append(flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
         gstruct = model._weights_struct(dict(zip((n for n, _ in model.named_parameters()), grads)))
         weights = model._weights_struct()
         rc = model._lib.dygnn_dygformer_backward(C.byref(model._cfg), C.byref(weights), C.byref(gstruct), g_src.data_ptr(), g_dst.data_ptr(), ctx.B,
@@ -93,7 +99,7 @@ class _TrainFunction(torch.autograd.Function):
                                                  _capi.current_stream_ptr())
         _capi.check(rc)
         ctx.ws = None
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 class DyGFormer(nn.Module):
@@ -171,7 +177,8 @@ class DyGFormer(nn.Module):
             seed = getattr(self, "_fixed_dropout_seed", None)             # tests pin the masks; normally torch.manual_seed governs them
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            return _TrainFunction.apply(self, src, dst, tms, p_drop, seed, *self.parameters())
+            seq_lens = self._seq_lens_side_stream(src_node_ids, dst_node_ids, node_interact_times, src, dst, tms, dev)
+            return _TrainFunction.apply(self, src, dst, tms, p_drop, seed, seq_lens, *self.parameters())
         out_src = torch.empty((B, self.node_feat_dim), dtype=torch.float32, device=dev)
         out_dst = torch.empty_like(out_src)
         if B == 0:
@@ -207,6 +214,39 @@ class DyGFormer(nn.Module):
         N, B = src.shape
         a, b = self.compute_src_dst_node_temporal_embeddings(src.reshape(-1), dst.reshape(-1), tms.reshape(-1), _group_size=B)
         return a.reshape(N, B, -1), b.reshape(N, B, -1)
+
+    def _seq_lens_side_stream(self, src_in, dst_in, t_in, src, dst, tms, dev):
+        """(S_src, S_dst) of this call, computed on a side stream so that the training forward does not have to synchronise the main
+        stream (which would serialise the host's launch work with everything still queued on the GPU).  Host inputs are uploaded a
+        second time on the side stream; device inputs make the side stream wait for the main stream's copy of them."""
+        side = getattr(self, "_side", None)
+        if side is None or side.device != dev:
+            side = self._side = torch.cuda.Stream(dev)
+        L, P = self.max_input_sequence_length, self.patch_size
+        B = src.numel()
+        host = not any(isinstance(x, torch.Tensor) for x in (src_in, dst_in, t_in))
+        ev = None
+        if not host:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            if host:
+                nodes = torch.from_numpy(np.concatenate([np.asarray(src_in, dtype=np.int64), np.asarray(dst_in, dtype=np.int64)])).to(dev)
+                times = torch.from_numpy(np.concatenate([np.asarray(t_in, dtype=np.float64)] * 2)).to(dev)
+            else:
+                side.wait_event(ev)
+                nodes, times = torch.cat([src, dst]), torch.cat([tms, tms])
+            hist = torch.empty(2 * B, dtype=torch.int32, device=dev)
+            end = torch.empty(2 * B, dtype=torch.int64, device=dev)
+            maxw = torch.zeros(2, dtype=torch.int32, device=dev)
+            csr = self.neighbor_sampler.csr.on_device(dev)
+            for half in (0, 1):
+                sl = slice(half * B, (half + 1) * B)
+                _capi.check(self._lib.dygnn_window_lengths(csr, nodes[sl].data_ptr(), times[sl].data_ptr(), B, L, hist[sl].data_ptr(),
+                                                           end[sl].data_ptr(), maxw[half:half + 1].data_ptr(), side.cuda_stream))
+            m = maxw.cpu()                               # synchronises the side stream only
+        S = [int(v) + 1 for v in m.tolist()]
+        return tuple(s_ + (P - s_ % P) % P for s_ in S)
 
     # ---- plumbing ------------------------------------------------------------------------------
     def _device(self) -> torch.device:

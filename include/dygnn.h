@@ -262,7 +262,8 @@ int dygnn_tgn_forward(const dygnn_tgat_config* cfg_host, const dygnn_tgat_weight
  * generator keyed by `seed` (statistically, not bitwise, the reference's torch masks; dropout_p = 0 reproduces the eval
  * forward).  It keeps every activation the backward pass needs in `workspace` (size from
  * dygnn_dygformer_train_workspace_bytes; must stay untouched until dygnn_dygformer_backward of the same call returns) and
- * writes this call's padded lengths (S_src, S_dst) to seq_lens_host[2] (one host synchronisation).
+ * writes this call's padded lengths (S_src, S_dst) to seq_lens_host[2] (one host synchronisation of `stream`) — unless the caller
+ * passes them in (both > 0, e.g. obtained with dygnn_window_lengths on a side stream), in which case the call stays asynchronous.
  * dygnn_dygformer_backward: `grads` has the layout of dygnn_dygformer_weights but its pointers are WRITABLE device buffers
  * of the parameter shapes; every one is overwritten with d(sum(out_src*grad_out_src) + sum(out_dst*grad_out_dst))/dparam.
  * The feature tables receive no gradient (constants in the reference, models/DyGFormer.py:28-29). */
