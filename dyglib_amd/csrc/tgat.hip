@@ -5,10 +5,9 @@
 // its k most recent neighbours.  Here the recursion is unrolled top-down into level sets (level L = the 2B query nodes,
 // level l-1 = [level-l nodes ; their k neighbours]; neighbour times are the float32 values the sampler returns,
 // models/TGAT.py:107-110) and evaluated bottom-up, one batched pass per layer:
-//   sample_recent -> build [h_nbr | edge | time] rows -> K/V projection (fp32-MFMA GEMM) -> masked attention over the k
-//   keys -> residual_fc + residual + LayerNorm -> MergeLayer (two GEMMs).
-// This round's version keeps the per-layer activations in HBM (correctness + first measurement); fusing the gather with
-// the K/V GEMM is the next step.
+//   sample_recent -> query projection -> W_k^T q per head -> attention over the k neighbours' INPUT rows (gathered on the
+//   fly; K and V are never materialised, see k_tgat_attn_lin) -> W_v z per head -> residual_fc + residual + LayerNorm ->
+//   MergeLayer.  All products go through the library's general fp32-MFMA GEMM (gemm.h).
 #include "common.h"
 #include "gemm.h"
 
@@ -100,19 +99,6 @@ __global__ __launch_bounds__(256) void k_tgat_inputs(const float* __restrict__ h
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// K/V projection fused with its input gather: kv[r][nb*Dq + :] = W_nb . [h(nbr) | edge | cos(w dt + b)]  (nb = 0 key,
-// 1 value; bias-free, models/modules.py:126-128,150-163), the [n*k][Fn+Fe+Ft] input never exists in memory.
-// One workgroup = 8 waves x 32 rows; wave: 2 row tiles x NT column tiles of accumulators.  Transposed product
-// (A operand = weight fragments, B operand = the row's features): the 17 fragments of a 16-wide k-chunk are shared by
-// all 8 waves, so they are staged through an LDS ring by LDS-DMA (8 k-chunks deep) and every fragment read feeds 8
-// MFMAs; the B operand is gathered straight from the tables / computed (time encoding) four chunks ahead.
-// ------------------------------------------------------------------------------------------------
-constexpr int64_t kLinAttnMinRows = 32768;   // levels with at least this many neighbour rows use the linearity-based attention
-constexpr int kKvNT = 17;            // column tiles per workgroup (Dq <= 272)
-constexpr int kKvSlots = 8;          // ring depth in k-chunks
-constexpr int kKvLds = kKvSlots * kKvNT * 1024;
-
 __device__ __attribute__((noinline)) float cos_libm(float x) { return cosf(x); }
 __device__ __forceinline__ float cos_time_t(float x) {      // same range reduction + polynomial as dygformer_fused3.hip
     if (!(fabsf(x) <= 3.0e7f)) return cos_libm(x);
@@ -133,125 +119,6 @@ __device__ __forceinline__ float cos_time_t(float x) {      // same range reduct
     r = fmaf(r, z, -19.739208802178716f);
     r = fmaf(r, z, 1.0f);
     return flip ? -r : r;
-}
-
-// weight fragments [nb][k-chunk][tile][64 lanes x 4]: lane (c,g), element t = W_nb[16 tile + c][16 chunk + 4g + t]
-__global__ void k_pack_kv(const float* __restrict__ wk, const float* __restrict__ wv, int Dq, int Dkv, int KC, float* __restrict__ dst) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)2 * KC * kKvNT * 256;
-    if (idx >= total) return;
-    const int t = idx & 3, lane = (idx >> 2) & 63;
-    const int64_t f = idx >> 8;
-    const int tile = (int)(f % kKvNT), kc = (int)((f / kKvNT) % KC), nb = (int)(f / ((int64_t)kKvNT * KC));
-    const int row = 16 * tile + (lane & 15), col = 16 * kc + 4 * (lane >> 4) + t;
-    const float* w = nb ? wv : wk;
-    dst[idx] = (row < Dq && col < Dkv) ? w[(size_t)row * Dkv + col] : 0.f;
-}
-
-__global__ __launch_bounds__(512, 2) void k_tgat_kv(const float* __restrict__ h_lower, const float* __restrict__ node_feat,
-                                                      const float* __restrict__ edge_feat, const int32_t* __restrict__ lower_ids,
-                                                      const int32_t* __restrict__ nbr_eid, const float* __restrict__ nbr_dt,
-                                                      const float* __restrict__ tw, const float* __restrict__ tb, int64_t n, int k, int Fn, int Fe,
-                                                      int Ft, const float* __restrict__ wfrag, int KC, int Dq, float* __restrict__ kv) {
-    extern __shared__ __attribute__((aligned(16))) float ring[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 15, g = lane >> 4;
-    const int nb = blockIdx.y;
-    const int64_t R = n * k;
-    const int64_t m0 = (int64_t)blockIdx.x * 256 + wave * 32;
-    const int Kkv = Fn + Fe + Ft;
-    // this lane's two rows
-    const float* hp[2]; const float* ep[2]; float dt[2]; bool rv[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t r = m0 + 16 * j + c;
-        rv[j] = r < R;
-        const int64_t rr = rv[j] ? r : 0;
-        const int64_t le = n + rr;
-        hp[j] = h_lower ? h_lower + le * Fn : node_feat + (size_t)lower_ids[le] * Fn;       // layer 1: raw features
-        ep[j] = edge_feat + (size_t)nbr_eid[rr] * Fe;
-        dt[j] = nbr_dt[rr];
-    }
-    auto fetch = [&](int j, int kc) -> f4 {
-        const int kk = 16 * kc + 4 * g;
-        if (!rv[j] || kk >= Kkv) return f4{0.f, 0.f, 0.f, 0.f};
-        if (kk < Fn) return *reinterpret_cast<const f4*>(hp[j] + kk);
-        if (kk < Fn + Fe) return *reinterpret_cast<const f4*>(ep[j] + (kk - Fn));
-        const int f = kk - Fn - Fe;
-        const f4 w = *reinterpret_cast<const f4*>(tw + f), b = *reinterpret_cast<const f4*>(tb + f);
-        f4 r;
-        r.x = cos_time_t(fmaf(dt[j], w.x, b.x)); r.y = cos_time_t(fmaf(dt[j], w.y, b.y));
-        r.z = cos_time_t(fmaf(dt[j], w.z, b.z)); r.w = cos_time_t(fmaf(dt[j], w.w, b.w));
-        return r;
-    };
-    const float* wsrc = wfrag + (size_t)nb * KC * kKvNT * 256 + lane * 4;
-    auto issue_stage = [&](int s) {        // k-chunk s -> ring slot s % 8; this wave's fragments wave, wave+8, wave+16
-        if (s < KC) {
-            for (int f = wave; f < kKvNT; f += 8)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + ((size_t)s * kKvNT + f) * 256),
-                                                 (__attribute__((address_space(3))) void*)(ring + ((s % kKvSlots) * kKvNT + f) * 256), 16, 0, 0);
-        }
-    };
-#pragma unroll
-    for (int s = 0; s < kKvSlots - 1; ++s) issue_stage(s);
-    constexpr int DB = 4;                  // B operands in flight (k-chunks ahead)
-    f4 bq[DB][2];
-#pragma unroll
-    for (int u = 0; u < DB; ++u) { bq[u][0] = fetch(0, u); bq[u][1] = fetch(1, u); }
-    f4 acc[2][kKvNT];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < kKvNT; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
-    const float* rl = ring + lane * 4;
-    for (int kc0 = 0; kc0 < KC; kc0 += DB) {
-#pragma unroll
-        for (int u = 0; u < DB; ++u) {
-            const int kc = kc0 + u;
-            if (kc < KC) {
-                // stage kc was issued >= 7 iterations ago: everything but this wave's youngest operations has landed; the
-                // barrier publishes the stage and frees the slot of stage kc-1 for the DMA issued right after it
-                if (kc + kKvSlots < KC) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // tail: no younger DMAs to count on
-                issue_stage(kc + kKvSlots - 1);
-                const f4 b0 = bq[u][0], b1 = bq[u][1];
-                bq[u][0] = fetch(0, kc + DB); bq[u][1] = fetch(1, kc + DB);
-                const float* fr = rl + (size_t)((kc % kKvSlots) * kKvNT) * 256;
-                f4 fs[2][4];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) fs[0][v] = *reinterpret_cast<const f4*>(fr + v * 256);
-#pragma unroll
-                for (int q = 0; q < 5; ++q) {              // tiles 0-3, 4-7, 8-11, 12-15, 16
-                    const int i0 = 4 * q, nn = q < 4 ? 4 : 1;
-                    if (q + 1 < 5) {
-                        const int n2 = q + 1 < 4 ? 4 : 1;
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) if (v < n2) fs[(q + 1) & 1][v] = *reinterpret_cast<const f4*>(fr + (4 * (q + 1) + v) * 256);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v)
-                            if (v < nn) {
-                                acc[0][i0 + v] = tmfma(fs[q & 1][v][t], b0[t], acc[0][i0 + v]);
-                                acc[1][i0 + v] = tmfma(fs[q & 1][v][t], b1[t], acc[1][i0 + v]);
-                            }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-    }
-    // accumulator tile = kv^T[col = 16i + 4g + r][row = c]: four consecutive columns per lane
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t r = m0 + 16 * j + c;
-        if (r >= R) continue;
-        float* o = kv + (size_t)r * 2 * Dq + (size_t)nb * Dq + 4 * g;
-#pragma unroll
-        for (int i = 0; i < kKvNT; ++i)
-            if (16 * i + 4 * g < Dq) *reinterpret_cast<f4*>(o + 16 * i) = acc[j][i];
-    }
 }
 
 // C[M][N] = act(A[M][K] . W[N][K]^T + bias): fp32 MFMA, operands straight from global memory (both are K-contiguous, so
@@ -310,64 +177,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ A, co
             }
         }
     }
-}
-
-// one wave per node: scores over the k keys per head, * head_dim^-0.5, masked_fill(id == 0, -1e10), softmax, weighted
-// sum of V (models/modules.py:168-191).  q [n][H*hd], kv [n*k][2*H*hd] (K then V), out [n][H*hd]
-__global__ __launch_bounds__(256) void k_tgat_attention(const float* __restrict__ q, const float* __restrict__ kv, const int32_t* __restrict__ lower_ids,
-                                                          int64_t n, int k, int H, int hd, float scale, float* __restrict__ out) {
-    // Lanes sweep a key's row as float4 (coalesced): with D = H*hd floats per half, float4 index x < D/4 is the K part,
-    // D/4 <= x < D/2 the V part.  Pass A: scores (per-head wave reductions), softmax; pass B: weighted sum of V, every lane
-    // owning the output float4s of its own column indices.  Needs hd % 4 == 0 and D/4 <= 128.
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
-    if (i >= n) return;
-    float* pw = reinterpret_cast<float*>(smem) + wave * H * k;       // [H][k] scores -> probabilities
-    const int D = H * hd, D4 = D >> 2, hd4 = hd >> 2;
-    const f4* q4 = reinterpret_cast<const f4*>(q + i * D);
-    // this lane's K columns: x0 = lane, x1 = lane + 64 (when < D4), their heads, and the query values
-    const int x0 = lane, x1 = lane + 64;
-    const bool v0 = x0 < D4, v1 = x1 < D4;
-    const f4 qa = v0 ? q4[x0] : f4{0.f, 0.f, 0.f, 0.f}, qb = v1 ? q4[x1] : f4{0.f, 0.f, 0.f, 0.f};
-    const int h0 = v0 ? x0 / hd4 : -1, h1 = v1 ? x1 / hd4 : -1;
-    for (int j = 0; j < k; ++j) {
-        const f4* row = reinterpret_cast<const f4*>(kv + (size_t)(i * k + j) * 2 * D);
-        float pa = 0.f, pb = 0.f;
-        if (v0) { const f4 kk = row[x0]; pa = fmaf(qa.x, kk.x, fmaf(qa.y, kk.y, fmaf(qa.z, kk.z, qa.w * kk.w))); }
-        if (v1) { const f4 kk = row[x1]; pb = fmaf(qb.x, kk.x, fmaf(qb.y, kk.y, fmaf(qb.z, kk.z, qb.w * kk.w))); }
-        for (int h = 0; h < H; ++h) {
-            float s = (h0 == h ? pa : 0.f) + (h1 == h ? pb : 0.f);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            if (lane == 0) {
-                s *= scale;                                               // modules.py:173
-                if (lower_ids[n + i * k + j] == 0) s = -1e10f;            // modules.py:176-184
-                pw[h * k + j] = s;
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < H) {                                                       // softmax over the k keys of head `lane`
-        float mx = -INFINITY;
-        for (int j = 0; j < k; ++j) mx = fmaxf(mx, pw[lane * k + j]);
-        float sum = 0.f;
-        for (int j = 0; j < k; ++j) { const float e = expf(pw[lane * k + j] - mx); pw[lane * k + j] = e; sum += e; }
-        const float inv = 1.0f / sum;
-        for (int j = 0; j < k; ++j) pw[lane * k + j] *= inv;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    f4 oa = f4{0.f, 0.f, 0.f, 0.f}, ob = f4{0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < k; ++j) {
-        const f4* row = reinterpret_cast<const f4*>(kv + (size_t)(i * k + j) * 2 * D) + D4;     // V half
-        if (v0) { const float p = pw[h0 * k + j]; const f4 vv = row[x0]; oa.x = fmaf(p, vv.x, oa.x); oa.y = fmaf(p, vv.y, oa.y); oa.z = fmaf(p, vv.z, oa.z); oa.w = fmaf(p, vv.w, oa.w); }
-        if (v1) { const float p = pw[h1 * k + j]; const f4 vv = row[x1]; ob.x = fmaf(p, vv.x, ob.x); ob.y = fmaf(p, vv.y, ob.y); ob.z = fmaf(p, vv.z, ob.z); ob.w = fmaf(p, vv.w, ob.w); }
-    }
-    f4* o4 = reinterpret_cast<f4*>(out + i * D);
-    if (v0) o4[x0] = oa;
-    if (v1) o4[x1] = ob;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -574,8 +383,7 @@ struct TgatPlan {
     int64_t n[DYGNN_MAX_LAYERS + 1];       // level sizes: n[L] = 2B, n[l-1] = n[l] * (1 + k)
     // byte offsets
     size_t ids[DYGNN_MAX_LAYERS + 1], times[DYGNN_MAX_LAYERS + 1], eid[DYGNN_MAX_LAYERS + 1], dt[DYGNN_MAX_LAYERS + 1], h[DYGNN_MAX_LAYERS + 1];
-    size_t kv_in, q_in, kv, q, att, fc, merge_in, hid, kvw, qk, z, total;
-    int KC;
+    size_t q_in, q, att, fc, merge_in, hid, qk, z, total;
 };
 
 static TgatPlan make_tgat_plan(const dygnn_tgat_config& c, int64_t B) {
@@ -594,15 +402,7 @@ static TgatPlan make_tgat_plan(const dygnn_tgat_config& c, int64_t B) {
         p.dt[l] = l >= 1 ? take((size_t)p.n[l] * p.k * sizeof(float)) : 0;
     }
     const int64_t nmax = p.L >= 1 ? p.n[1] : 0;                        // the largest computed level
-    p.kv_in = 0;                                                       // the K/V input rows are gathered inside k_tgat_kv
-    p.KC = (p.Dkv + 15) / 16;
-    p.kvw = take((size_t)2 * p.KC * kKvNT * 256 * sizeof(float));      // packed key/value weights of the layer being evaluated
     p.q_in = take((size_t)nmax * p.Dq * sizeof(float));
-    {   // K | V of the largest level that still takes the fused K/V kernel (levels of >= kLinAttnMinRows rows never materialise them)
-        int64_t small = 0;
-        for (int l = 1; l <= p.L; ++l) if (p.n[l] * p.k < kLinAttnMinRows && p.n[l] > small) small = p.n[l];
-        p.kv = take((size_t)small * p.k * 2 * p.Dq * sizeof(float));
-    }
     p.qk = take((size_t)nmax * p.H * p.Dkv * sizeof(float));
     p.z = take((size_t)nmax * p.H * p.Dkv * sizeof(float));
     p.q = take((size_t)nmax * p.Dq * sizeof(float));
@@ -706,39 +506,21 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
                            F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, (float*)nullptr, F32(p.q_in));     // query rows
         DYGNN_LAUNCH_CHECK();
         if (int rc = gemm_nt<false>(F32(p.q_in), Lw.query_w, nullptr, F32(p.q), n, p.Dq, p.Dq, p.Dq, s)) return rc;
-        if (n * p.k >= kLinAttnMinRows) {
-            // qk[i][h] = W_k,h^T q_ih : per head [n][hd] x [hd][Dkv] (rows h*hd .. of key_w), one batched launch over the heads
-            if (int rc = train::mm(s, F32(p.q), p.Dq, false, Lw.key_w, p.Dkv, false, F32(p.qk), p.H * p.Dkv, (int)n, p.Dkv, p.hd, nullptr, 1.f, 0.f, p.H, p.H, 0, p.hd,
-                                   0, (int64_t)p.hd * p.Dkv, 0, p.Dkv)) return rc;
-            const dim3 grid((unsigned)ceil_div(n, 4));
-            const size_t lds = (size_t)4 * p.H * p.k * sizeof(float);
-            if (p.k <= 20)
-                hipLaunchKernelGGL((k_tgat_attn_lin<20>), grid, dim3(256), lds + (size_t)4 * 20 * p.Ft * sizeof(float), s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]), F32(p.dt[l]),
-                                   w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z));
-            else
-                hipLaunchKernelGGL((k_tgat_attn_lin<0>), grid, dim3(256), lds, s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]), F32(p.dt[l]),
-                                   w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z));
-            DYGNN_LAUNCH_CHECK();
-            // att[i][h*hd ..] = W_v,h z_ih : per head [n][Dkv] x [Dkv][hd]
-            if (int rc = train::mm(s, F32(p.z), p.H * p.Dkv, false, Lw.value_w, p.Dkv, true, F32(p.att), p.Dq, (int)n, p.hd, p.Dkv, nullptr, 1.f, 0.f, p.H, p.H, 0, p.Dkv,
-                                   0, (int64_t)p.hd * p.Dkv, 0, p.hd)) return rc;
-        } else {
-            // small levels (the top TGAT layer, TGN's single layer): K and V by the fused gather + projection kernel, then attention
-            const int64_t tot = (int64_t)2 * p.KC * kKvNT * 256;
-            hipLaunchKernelGGL(k_pack_kv, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s, Lw.key_w, Lw.value_w, p.Dq, p.Dkv, p.KC, F32(p.kvw));
-            DYGNN_LAUNCH_CHECK();
-            static bool attr_set = false;
-            if (!attr_set) {
-                DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tgat_kv), hipFuncAttributeMaxDynamicSharedMemorySize, kKvLds));
-                attr_set = true;
-            }
-            hipLaunchKernelGGL(k_tgat_kv, dim3((unsigned)ceil_div(n * p.k, 256), 2), dim3(512), kKvLds, s, h_lower, node_feat, edge_feat, I32(p.ids[l - 1]),
-                               I32(p.eid[l]), F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, F32(p.kvw), p.KC, p.Dq, F32(p.kv));
-            DYGNN_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_tgat_attention, dim3((unsigned)ceil_div(n, 4)), dim3(256), (size_t)4 * p.H * p.k * sizeof(float), s, F32(p.q), F32(p.kv),
-                               I32(p.ids[l - 1]), n, p.k, p.H, p.hd, scale, F32(p.att));
-            DYGNN_LAUNCH_CHECK();
-        }
+        // qk[i][h] = W_k,h^T q_ih : per head [n][hd] x [hd][Dkv] (rows h*hd .. of key_w), one batched launch over the heads
+        if (int rc = train::mm(s, F32(p.q), p.Dq, false, Lw.key_w, p.Dkv, false, F32(p.qk), p.H * p.Dkv, (int)n, p.Dkv, p.hd, nullptr, 1.f, 0.f, p.H, p.H, 0, p.hd,
+                               0, (int64_t)p.hd * p.Dkv, 0, p.Dkv)) return rc;
+        const dim3 grid((unsigned)ceil_div(n, 4));
+        const size_t lds = (size_t)4 * p.H * p.k * sizeof(float);
+        if (p.k <= 20)
+            hipLaunchKernelGGL((k_tgat_attn_lin<20>), grid, dim3(256), lds + (size_t)4 * 20 * p.Ft * sizeof(float), s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]), F32(p.dt[l]),
+                               w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z));
+        else
+            hipLaunchKernelGGL((k_tgat_attn_lin<0>), grid, dim3(256), lds, s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]), F32(p.dt[l]),
+                               w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z));
+        DYGNN_LAUNCH_CHECK();
+        // att[i][h*hd ..] = W_v,h z_ih : per head [n][Dkv] x [Dkv][hd]
+        if (int rc = train::mm(s, F32(p.z), p.H * p.Dkv, false, Lw.value_w, p.Dkv, true, F32(p.att), p.Dq, (int)n, p.hd, p.Dkv, nullptr, 1.f, 0.f, p.H, p.H, 0, p.Dkv,
+                               0, (int64_t)p.hd * p.Dkv, 0, p.hd)) return rc;
         if (int rc = gemm_nt<false>(F32(p.att), Lw.res_w, Lw.res_b, F32(p.fc), n, p.Dq, p.Dq, p.Dq, s)) return rc;
         hipLaunchKernelGGL(k_tgat_post, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, s, F32(p.fc), F32(p.q_in), Lw.ln_w, Lw.ln_b, node_feat, I32(p.ids[l - 1]),
                            n, p.Dq, p.Fn, F32(p.merge_in));
