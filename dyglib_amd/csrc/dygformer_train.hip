@@ -31,6 +31,7 @@ struct MM {
     int M, N, K, lda, ldb, ldc, transA, transB;
     float alpha, beta;
     int H; int64_t sAb, sAh, sBb, sBh, sCb, sCh;
+    int relu;               // epilogue max(v, 0) (not combined with split-K)
     int ksplit, kchunk;     // split-K: blockIdx.z = batch * ksplit + part; part sums k in [part*kchunk, +kchunk) and adds atomically
 };
 
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256) void k_mm(const MM p) {
             float v = p.alpha * acc[nt][r] + bv;
             if (p.ksplit > 1) { atomicAdd(&C[(size_t)m * p.ldc + n], v); continue; }
             if (p.beta != 0.f) v += p.beta * C[(size_t)m * p.ldc + n];
+            if (p.relu) v = fmaxf(v, 0.f);
             C[(size_t)m * p.ldc + n] = v;
         }
     }
@@ -219,17 +221,18 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
                 float v = p.alpha * acc[i][j][r] + bv;
                 if (p.ksplit > 1) { atomicAdd(&C[(size_t)m * p.ldc + n], v); continue; }
                 if (p.beta != 0.f) v += p.beta * C[(size_t)m * p.ldc + n];
+                if (p.relu) v = fmaxf(v, 0.f);
                 C[(size_t)m * p.ldc + n] = v;
             }
     }
 }
 
 int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb, bool tB, float* C, int ldc, int M, int N, int K, const float* bias, float alpha,
-       float beta, int batch, int H, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh) {
+       float beta, int batch, int H, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, bool relu) {
     if (M <= 0 || N <= 0 || batch <= 0) return DYGNN_OK;
-    MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh, 1, K};
+    MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh, relu ? 1 : 0, 1, K};
     // weight gradients: small output, K = all rows of the call -> split K over workgroups, partial sums meet by atomicAdd
-    if (batch == 1 && K >= 2048) {
+    if (batch == 1 && K >= 2048 && !relu) {
         p.kchunk = 256;
         p.ksplit = (K + p.kchunk - 1) / p.kchunk;
         if (beta == 0.f) DYGNN_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s));
