@@ -228,14 +228,14 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
 }
 
 int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb, bool tB, float* C, int ldc, int M, int N, int K, const float* bias, float alpha,
-       float beta, int batch, int H, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, bool relu) {
+       float beta, int batch, int H, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, bool relu, bool c_is_zero) {
     if (M <= 0 || N <= 0 || batch <= 0) return DYGNN_OK;
     MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh, relu ? 1 : 0, 1, K};
     // weight gradients: small output, K = all rows of the call -> split K over workgroups, partial sums meet by atomicAdd
     if (batch == 1 && K >= 2048 && !relu) {
         p.kchunk = 256;
         p.ksplit = (K + p.kchunk - 1) / p.kchunk;
-        if (beta == 0.f) DYGNN_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s));
+        if (beta == 0.f && !c_is_zero) DYGNN_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s));
         p.beta = 0.f;
     }
     batch *= p.ksplit;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ A, int
     if (r0 == 0 && n < N) atomicAdd(&out[n], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 static int colsum(hipStream_t s, const float* A, int lda, int64_t M, int N, float* out, bool accumulate = false) {
-    if (!accumulate) DYGNN_HIP(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s));
+    (void)accumulate;        // gradient buffers arrive zeroed (dygnn_dygformer_backward contract): every call accumulates
     hipLaunchKernelGGL(k_colsum, dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 256)), dim3(256), 0, s, A, lda, M, N, out);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
@@ -790,21 +790,19 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
         float* dQKV = F32(p.dQKV);      // [M][3D]
         // X_{l+1} = X1 + drop(F2), F2 = Hact W2^T + b2
         EW(k_drop_bwd, M * D, dX, M * D, dr, (uint32_t)(4 * l + 3), dA);                                                       // dF2
-        if (int rc = mm(s, dA, D, true, F32(L.hact), 4 * D, false, G(Lg.ffn1_weight), 4 * D, D, 4 * D, (int)M)) return rc;     // dW2 [D][4D]
+        if (int rc = mm(s, dA, D, true, F32(L.hact), 4 * D, false, G(Lg.ffn1_weight), 4 * D, D, 4 * D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true)) return rc;     // dW2 [D][4D]
         if (int rc = colsum(s, dA, D, M, D, G(Lg.ffn1_bias))) return rc;
         if (int rc = mm(s, dA, D, false, Lw.ffn1_weight, 4 * D, false, dH, 4 * D, (int)M, 4 * D, D)) return rc;                 // dHact
         EW(k_gelu_drop_bwd, M * 4 * D, dH, F32(L.hpre), M * 4 * D, dr, (uint32_t)(4 * l + 2));                                 // dHpre
-        if (int rc = mm(s, dH, 4 * D, true, F32(L.xn1), D, false, G(Lg.ffn0_weight), D, 4 * D, D, (int)M)) return rc;           // dW1 [4D][D]
+        if (int rc = mm(s, dH, 4 * D, true, F32(L.xn1), D, false, G(Lg.ffn0_weight), D, 4 * D, D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true)) return rc;           // dW1 [4D][D]
         if (int rc = colsum(s, dH, 4 * D, M, 4 * D, G(Lg.ffn0_bias))) return rc;
         if (int rc = mm(s, dH, 4 * D, false, Lw.ffn0_weight, D, false, dBf, D, (int)M, D, 4 * D)) return rc;                    // dxn1
-        DYGNN_HIP(hipMemsetAsync(G(Lg.norm1_weight), 0, D * sizeof(float), s));
-        DYGNN_HIP(hipMemsetAsync(G(Lg.norm1_bias), 0, D * sizeof(float), s));
         hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)ceil_div(M, 64)), dim3(256), 8 * D * sizeof(float), s, dBf, F32(L.x1), F32(L.m1), F32(L.r1), Lw.norm1_weight, M, D,
                            dX, G(Lg.norm1_weight), G(Lg.norm1_bias));                                                          // dX is now dX1
         DYGNN_LAUNCH_CHECK();
         // X1 = Xin + drop(Ao), Ao = Oa Wo^T + bo
         EW(k_drop_bwd, M * D, dX, M * D, dr, (uint32_t)(4 * l + 1), dA);                                                       // dAo
-        if (int rc = mm(s, dA, D, true, F32(L.oa), D, false, G(Lg.out_proj_weight), D, D, D, (int)M)) return rc;
+        if (int rc = mm(s, dA, D, true, F32(L.oa), D, false, G(Lg.out_proj_weight), D, D, D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true)) return rc;
         if (int rc = colsum(s, dA, D, M, D, G(Lg.out_proj_bias))) return rc;
         if (int rc = mm(s, dA, D, false, Lw.out_proj_weight, D, false, dBf, D, (int)M, D, D)) return rc;                        // dOa
         // attention: Oa_bh = Pd_bh V_bh ; S_bh = scale Q_bh K_bh^T
@@ -821,11 +819,9 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
                         (int64_t)T * T, (int64_t)T * 3 * D, hd, (int64_t)T * 3 * D, hd)) return rc;
         if (int rc = mm(s, F32(L.S), T, true, F32(L.qkv), 3 * D, false, dQKV + D, 3 * D, T, hd, T, nullptr, scale, 0.f, (int)(B * H), H, (int64_t)H * T * T,
                         (int64_t)T * T, (int64_t)T * 3 * D, hd, (int64_t)T * 3 * D, hd)) return rc;
-        if (int rc = mm(s, dQKV, 3 * D, true, F32(L.xn0), D, false, G(Lg.in_proj_weight), D, 3 * D, D, (int)M)) return rc;      // dWin [3D][D]
+        if (int rc = mm(s, dQKV, 3 * D, true, F32(L.xn0), D, false, G(Lg.in_proj_weight), D, 3 * D, D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true)) return rc;      // dWin [3D][D]
         if (int rc = colsum(s, dQKV, 3 * D, M, 3 * D, G(Lg.in_proj_bias))) return rc;
         if (int rc = mm(s, dQKV, 3 * D, false, Lw.in_proj_weight, D, false, dA, D, (int)M, D, 3 * D)) return rc;                // dxn0
-        DYGNN_HIP(hipMemsetAsync(G(Lg.norm0_weight), 0, D * sizeof(float), s));
-        DYGNN_HIP(hipMemsetAsync(G(Lg.norm0_bias), 0, D * sizeof(float), s));
         hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)ceil_div(M, 64)), dim3(256), 8 * D * sizeof(float), s, dA, F32(p.X[l]), F32(L.m0), F32(L.r0), Lw.norm0_weight, M, D,
                            dX, G(Lg.norm0_weight), G(Lg.norm0_bias));                                                          // dX is now dX_l
         DYGNN_LAUNCH_CHECK();
@@ -837,13 +833,11 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
     const size_t PM[4] = {p.Pn, p.Pe, p.Pt, p.Pc};
     const int PK[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * C};
     for (int ch = 0; ch < 4; ++ch) {
-        if (int rc = mm(s, dX + ch * C, D, true, F32(PM[ch]), PK[ch], false, GW[ch], PK[ch], C, PK[ch], (int)M)) return rc;     // dW_ch [C][K]
+        if (int rc = mm(s, dX + ch * C, D, true, F32(PM[ch]), PK[ch], false, GW[ch], PK[ch], C, PK[ch], (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true)) return rc;     // dW_ch [C][K]
         if (int rc = colsum(s, dX + ch * C, D, M, C, GB[ch])) return rc;
     }
     // time encoder
     if (int rc = mm(s, dX + 2 * C, D, false, PW[2], PK[2], false, F32(p.dPt), PK[2], (int)M, PK[2], C)) return rc;
-    DYGNN_HIP(hipMemsetAsync(G(grads->time_w), 0, d.Ft * sizeof(float), s));
-    DYGNN_HIP(hipMemsetAsync(G(grads->time_b), 0, d.Ft * sizeof(float), s));
     hipLaunchKernelGGL(k_time_bwd, dim3((unsigned)B), dim3(256), 2 * d.Ft * sizeof(float), s, F32(p.dPt), I32(p.ids), F32(p.dts), w->time_w, w->time_b, B, Ss, Sd, Ts, T,
                        d.P, d.Ft, G(grads->time_w), G(grads->time_b));
     DYGNN_LAUNCH_CHECK();

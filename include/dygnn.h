@@ -265,7 +265,8 @@ int dygnn_tgn_forward(const dygnn_tgat_config* cfg_host, const dygnn_tgat_weight
  * writes this call's padded lengths (S_src, S_dst) to seq_lens_host[2] (one host synchronisation of `stream`) — unless the caller
  * passes them in (both > 0, e.g. obtained with dygnn_window_lengths on a side stream), in which case the call stays asynchronous.
  * dygnn_dygformer_backward: `grads` has the layout of dygnn_dygformer_weights but its pointers are WRITABLE device buffers
- * of the parameter shapes; every one is overwritten with d(sum(out_src*grad_out_src) + sum(out_dst*grad_out_dst))/dparam.
+ * of the parameter shapes that MUST BE ZERO on entry (the reductions accumulate into them); on return each holds
+ * d(sum(out_src*grad_out_src) + sum(out_dst*grad_out_dst))/dparam.
  * The feature tables receive no gradient (constants in the reference, models/DyGFormer.py:28-29). */
 size_t dygnn_dygformer_train_workspace_bytes(const dygnn_dygformer_config* cfg_host, int64_t batch);
 int dygnn_dygformer_train_forward(const dygnn_dygformer_config* cfg_host, const dygnn_dygformer_weights* w_host,
