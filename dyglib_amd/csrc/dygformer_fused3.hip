@@ -643,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
 #pragma unroll
                 for (int kt = 0; kt < TPW; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { sa[kt][r] = expf(sa[kt][r] - mx); sum += sa[kt][r]; }
+                    for (int r = 0; r < 4; ++r) { sa[kt][r] = __expf(sa[kt][r] - mx); sum += sa[kt][r]; }
                 sum += __shfl_xor(sum, 16, 64);
                 sum += __shfl_xor(sum, 32, 64);
                 const float inv = 1.0f / sum;
