@@ -133,6 +133,17 @@ extern "C" size_t dygnn_dygformer_workspace_bytes(const dygnn_dygformer_config* 
     return make_workspace_layout(d, batch).total;
 }
 
+// impl as in dygnn_dygformer_forward.  The fused kernels keep every activation on chip: they only need the per-query search results
+// (a few bytes per pair); the generic path also needs its HBM activation buffers (~29 KB per token).
+extern "C" size_t dygnn_dygformer_workspace_bytes_for(const dygnn_dygformer_config* cfg, int64_t batch, int32_t impl) {
+    if (check_config(cfg) != DYGNN_OK || batch < 0 || impl < 0 || impl > 3) return 0;
+    const Dims d = make_dims(*cfg);
+    const WorkspaceLayout wl = make_workspace_layout(d, batch);
+    const bool generic = impl == 1 || (impl == 0 && !fused3_supported(d) && !fused_supported(d)) || (impl == 2 && !fused_supported(d)) ||
+                         (impl == 3 && !fused3_supported(d));
+    return generic ? wl.total : wl.X;
+}
+
 extern "C" int dygnn_dygformer_pack(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, void* packed,
                                     size_t packed_bytes, dygnn_stream_t stream) {
     if (int rc = check_config(cfg)) return rc;
@@ -169,8 +180,9 @@ extern "C" int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg, const 
     DYGNN_REQUIRE(impl >= 0 && impl <= 3, "forward: impl must be 0 (auto), 1 (generic), 2 (fused, wave-pair layout) or 3 (fused, token-owner layout)");
     if (batch == 0) return DYGNN_OK;
     const WorkspaceLayout wl = make_workspace_layout(d, batch);
-    if (workspace_bytes < wl.total) {
-        set_error("forward: workspace too small (%zu < %zu bytes)", workspace_bytes, wl.total);
+    const size_t need = dygnn_dygformer_workspace_bytes_for(cfg, batch, impl);
+    if (workspace_bytes < need) {
+        set_error("forward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
         return DYGNN_E_WORKSPACE;
     }
     const PackedLayout pl = make_packed_layout(d);

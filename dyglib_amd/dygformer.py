@@ -314,10 +314,10 @@ class DyGFormer(nn.Module):
 
     def _workspace_for(self, B: int, dev) -> torch.Tensor:
         # one workspace per (batch size, stream): calls issued on different HIP streams may overlap
-        key = (B, torch.cuda.current_stream(dev).cuda_stream)
+        key = (B, int(self.impl), torch.cuda.current_stream(dev).cuda_stream)
         ws = self._workspace.get(key)
         if ws is None or ws.device != dev:
-            nbytes = self._lib.dygnn_dygformer_workspace_bytes(C.byref(self._cfg), B)
+            nbytes = self._lib.dygnn_dygformer_workspace_bytes_for(C.byref(self._cfg), B, int(self.impl))
             ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
             if len(self._workspace) > 16:
                 self._workspace.clear()

@@ -160,6 +160,9 @@ int dygnn_dygformer_pack(const dygnn_dygformer_config* cfg_host, const dygnn_dyg
                          void* packed, size_t packed_bytes, dygnn_stream_t stream);
 
 size_t dygnn_dygformer_workspace_bytes(const dygnn_dygformer_config* cfg_host, int64_t batch);
+/* the same for one implementation choice (`impl` of dygnn_dygformer_forward): the fused kernels need only the per-query search
+ * results, the generic path also its activation buffers; dygnn_dygformer_workspace_bytes is the size that serves every impl */
+size_t dygnn_dygformer_workspace_bytes_for(const dygnn_dygformer_config* cfg_host, int64_t batch, int32_t impl);
 
 /* One launch sequence for `batch` (src,dst,t) pairs.  group_size = G splits the pairs into consecutive
  * groups of G that are padded independently (each group has its own S_src/S_dst, models/DyGFormer.py:219-226):
