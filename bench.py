@@ -282,6 +282,7 @@ def main():
 
     if rank == 0 and world == 1:
         out["stages"] = sampler_stage(sampler, data, dev)           # stage-level number for the neighbour lookup
+        out["stages"].update(metrics_stage(dev))
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(params, mparams, node_feat, edge_feat, data, batches, L, P, args.cpu_seconds)
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
@@ -314,6 +315,24 @@ def sampler_stage(sampler, data, dev, n_queries: int = 400_000, k: int = 20, rep
     algo = float((8 * 64 * probes).sum() + 16 * np.minimum(deg, k).sum() + 20.0 * k * len(nodes_h) + 16 * len(nodes_h))
     return {"sampler_recent_k20_queries_per_s": round(len(nodes_h) / sec), "sampler_algorithmic_GBps": round(algo / sec / 1e9, 1),
             "sampler_frac_of_hbm_peak": round(algo / sec / 8.0e12, 4), "queries": len(nodes_h)}
+
+
+def metrics_stage(dev, groups: int = 237, n: int = 400, reps: int = 10) -> dict:
+    """AP + ROC AUC + BCELoss of `groups` evaluation batches (200 positive + 200 negative scores each) in one launch
+    (dygnn_link_metrics): batches/s, outside the headline metric (SURVEY §8(d) excludes the sklearn metrics)."""
+    from dyglib_amd import link_prediction_metrics_device
+    g = torch.Generator(device="cpu").manual_seed(0)
+    y = torch.cat([torch.ones(groups, n // 2), torch.zeros(groups, n // 2)], dim=1).to(dev)
+    p = torch.sigmoid(torch.randn(groups, n, generator=g)).to(dev)
+    link_prediction_metrics_device(p, y)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        link_prediction_metrics_device(p, y)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return {"metrics_batches_per_s": round(groups * reps / (e0.elapsed_time(e1) * 1e-3))}
 
 
 def cpu_baseline(params, mparams, node_feat, edge_feat, data, batches, L, P, budget_s):

@@ -9,7 +9,9 @@ The compute lives in dyglib_amd/csrc (C ABI: include/dygnn.h).  There is no CPU 
 from .synthetic import InteractionData  # noqa: F401
 
 __all__ = ["DyGFormer", "TGAT", "MemoryModel", "MergeLayer", "TimeEncoder", "NeighborSampler", "get_neighbor_sampler", "TemporalCSR",
-           "count_nodes_appearances", "InteractionData", "Data", "get_link_prediction_data"]
+           "count_nodes_appearances", "InteractionData", "Data", "get_link_prediction_data",
+           "get_link_prediction_metrics", "get_node_classification_metrics", "link_prediction_metrics_device",
+           "NegativeEdgeSampler", "get_idx_data_loader", "evaluate_model_link_prediction"]
 
 
 def __getattr__(name):
@@ -32,6 +34,12 @@ def __getattr__(name):
     if name in ("Data", "get_link_prediction_data"):
         from . import data_loader
         return getattr(data_loader, name)
+    if name in ("get_link_prediction_metrics", "get_node_classification_metrics", "link_prediction_metrics_device"):
+        from . import metrics
+        return getattr(metrics, name)
+    if name in ("NegativeEdgeSampler", "get_idx_data_loader", "evaluate_model_link_prediction"):
+        from . import evaluate
+        return getattr(evaluate, name)
     if name == "TemporalCSR":
         from .temporal_csr import TemporalCSR
         return TemporalCSR

@@ -20,7 +20,7 @@ INCLUDE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 LIB_NAME = "libdygnn_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
 SOURCES = ["csr_host.cpp", "sampler.hip", "cooccurrence.hip", "dygformer_generic.hip", "dygformer_fused.hip", "dygformer_fused3.hip", "dygformer_train.hip",
-           "dygformer_api.hip", "tgat.hip"]
+           "dygformer_api.hip", "tgat.hip", "metrics.hip"]
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-ffp-contract=off"]   # contractions are written explicitly (fmaf) where the oracle has them

@@ -1,0 +1,135 @@
+"""The evaluation loop around the hot path (reference evaluate_models_utils.py:18-153) and its negative edge sampler
+(utils/utils.py:305-495), with the reference's names and argument meaning.  What changes is where the work happens:
+the scores of a batch never leave the GPU (MergeLayer + sigmoid, BCELoss, average precision and ROC AUC are HIP
+kernels, dyglib_amd/csrc/metrics.hip), DyGFormer batches are grouped `fuse_batches` at a time into one launch, and the
+host synchronises once, at the end, instead of once per batch."""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .metrics import link_prediction_metrics_device
+
+
+class NegativeEdgeSampler(object):
+    """utils/utils.py:305-495, strategy 'random' (the reference's default, train_link_prediction.py:95-104): sources and
+    destinations drawn independently from the unique source / destination ids with the sampler's own RandomState, so a
+    seeded sampler returns the reference's negatives draw for draw.  'historical' / 'inductive' enumerate Python sets of
+    edge tuples, whose iteration order decides the result; they are not restated here and raise NotImplementedError."""
+
+    def __init__(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray, interact_times: np.ndarray = None,
+                 last_observed_time: float = None, negative_sample_strategy: str = "random", seed: int = None):
+        self.seed = seed
+        self.negative_sample_strategy = negative_sample_strategy
+        self.src_node_ids = src_node_ids
+        self.dst_node_ids = dst_node_ids
+        self.interact_times = interact_times
+        self.unique_src_node_ids = np.unique(src_node_ids)
+        self.unique_dst_node_ids = np.unique(dst_node_ids)
+        self.last_observed_time = last_observed_time
+        if negative_sample_strategy in ("historical", "inductive"):
+            raise NotImplementedError(f"negative_sample_strategy {negative_sample_strategy} is not available (only 'random')")
+        if negative_sample_strategy != "random":
+            raise ValueError(f"Not implemented error for negative_sample_strategy {negative_sample_strategy}!")   # utils/utils.py:375
+        if self.seed is not None:
+            self.random_state = np.random.RandomState(self.seed)
+
+    def sample(self, size: int, batch_src_node_ids: np.ndarray = None, batch_dst_node_ids: np.ndarray = None,
+               current_batch_start_time: float = 0.0, current_batch_end_time: float = 0.0):
+        return self.random_sample(size=size)
+
+    def random_sample(self, size: int):
+        rs = np.random if self.seed is None else self.random_state                 # utils/utils.py:384-389
+        src_idx = rs.randint(0, len(self.unique_src_node_ids), size)
+        dst_idx = rs.randint(0, len(self.unique_dst_node_ids), size)
+        return self.unique_src_node_ids[src_idx], self.unique_dst_node_ids[dst_idx]
+
+    def reset_random_state(self):
+        self.random_state = np.random.RandomState(self.seed)
+
+
+def get_idx_data_loader(indices_list: list, batch_size: int, shuffle: bool):
+    """utils/DataLoader.py:29-43: batches of indices, last batch kept (drop_last=False)."""
+    from torch.utils.data import DataLoader
+    return DataLoader(dataset=list(indices_list), batch_size=batch_size, shuffle=shuffle, drop_last=False)
+
+
+def _is_plain_bce(loss_func) -> bool:
+    return isinstance(loss_func, nn.BCELoss) and loss_func.reduction == "mean" and getattr(loss_func, "weight", None) is None
+
+
+def evaluate_model_link_prediction(model_name: str, model: nn.Module, neighbor_sampler, evaluate_idx_data_loader,
+                                   evaluate_neg_edge_sampler: NegativeEdgeSampler, evaluate_data, loss_func: nn.Module,
+                                   num_neighbors: int = 20, time_gap: int = 2000, fuse_batches: int = 32
+                                   ) -> Tuple[List[float], List[dict]]:
+    """evaluate_models_utils.py:18-153 for the models of this package (DyGFormer, TGAT, TGN): `model` is
+    nn.Sequential(backbone, MergeLayer); returns (evaluate_losses, evaluate_metrics) = one float and one
+    {'average_precision', 'roc_auc'} dict per batch, like the reference."""
+    assert evaluate_neg_edge_sampler.seed is not None                           # evaluate_models_utils.py:35
+    evaluate_neg_edge_sampler.reset_random_state()
+    if model_name not in ("DyGFormer", "TGAT", "TGN"):
+        raise ValueError(f"Wrong value for model_name {model_name}!")
+    model[0].set_neighbor_sampler(neighbor_sampler)
+    model.eval()
+    backbone, merge = model[0], model[1]
+    plain_bce = _is_plain_bce(loss_func)
+    results = []                                    # per launch: (ap, auc, loss, status) device tensors, in batch order
+
+    def score(groups_pos, groups_neg):
+        """groups_*: lists of equally sized (src, dst, t[, eid]) tuples -> predicts, labels [len, 2B]"""
+        n, B = len(groups_pos), len(groups_pos[0][0])
+        if model_name == "DyGFormer":
+            src = np.stack([g[0] for g in groups_pos] + [g[0] for g in groups_neg])
+            dst = np.stack([g[1] for g in groups_pos] + [g[1] for g in groups_neg])
+            tms = np.stack([g[2] for g in groups_pos] + [g[2] for g in groups_neg])
+            a, b = backbone.compute_src_dst_node_temporal_embeddings_many(src, dst, tms)
+            prob = merge.link_probabilities(a.reshape(2 * n * B, -1), b.reshape(2 * n * B, -1)).reshape(2, n, B)
+        else:
+            probs = []
+            for gp, gn in zip(groups_pos, groups_neg):
+                if model_name == "TGAT":
+                    pe = backbone.compute_src_dst_node_temporal_embeddings(gp[0], gp[1], gp[2], num_neighbors=num_neighbors)
+                    ne = backbone.compute_src_dst_node_temporal_embeddings(gn[0], gn[1], gn[2], num_neighbors=num_neighbors)
+                else:       # TGN: negatives first, they must not see the memories this batch's positives write (:85-107)
+                    ne = backbone.compute_src_dst_node_temporal_embeddings(gn[0], gn[1], gn[2], edge_ids=None, edges_are_positive=False,
+                                                                           num_neighbors=num_neighbors)
+                    pe = backbone.compute_src_dst_node_temporal_embeddings(gp[0], gp[1], gp[2], edge_ids=gp[3], edges_are_positive=True,
+                                                                           num_neighbors=num_neighbors)
+                probs.append(torch.stack([merge.link_probabilities(*pe), merge.link_probabilities(*ne)]))
+            prob = torch.stack(probs, dim=1)
+        predicts = torch.cat([prob[0], prob[1]], dim=1)                                     # :142
+        labels = torch.cat([torch.ones_like(prob[0]), torch.zeros_like(prob[1])], dim=1)    # :143
+        return predicts, labels
+
+    def flush(pos, neg):
+        if not pos:
+            return
+        predicts, labels = score(pos, neg)
+        ap, auc, loss, status = link_prediction_metrics_device(predicts, labels)
+        if not plain_bce:
+            loss = torch.stack([loss_func(input=predicts[i], target=labels[i]).double() for i in range(len(pos))])
+        results.append((ap, auc, loss, status))
+
+    with torch.no_grad():
+        pend_pos, pend_neg = [], []
+        for evaluate_data_indices in evaluate_idx_data_loader:
+            idx = evaluate_data_indices.numpy() if isinstance(evaluate_data_indices, torch.Tensor) else np.asarray(evaluate_data_indices)
+            src, dst = evaluate_data.src_node_ids[idx], evaluate_data.dst_node_ids[idx]
+            tms, eid = evaluate_data.node_interact_times[idx], evaluate_data.edge_ids[idx]
+            _, neg_dst = evaluate_neg_edge_sampler.sample(size=len(src))                    # :64-66 ('random')
+            if pend_pos and (len(pend_pos[0][0]) != len(src) or len(pend_pos) >= max(1, fuse_batches)):
+                flush(pend_pos, pend_neg)
+                pend_pos, pend_neg = [], []
+            pend_pos.append((src, dst, tms, eid))
+            pend_neg.append((src, neg_dst, tms, None))
+        flush(pend_pos, pend_neg)
+
+    if not results:
+        return [], []
+    ap, auc, loss, status = (torch.cat([r[i] for r in results]).cpu().numpy() for i in range(4))     # the only synchronisation
+    if status.any():
+        raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+    return [float(v) for v in loss], [{"average_precision": float(a), "roc_auc": float(u)} for a, u in zip(ap, auc)]

@@ -289,6 +289,19 @@ int dygnn_merge_layer_sigmoid(const float* a, const float* b, int64_t n, int32_t
                               const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
                               float* out, dygnn_stream_t stream);
 
+/* Evaluation metrics on the device, replacing the scikit-learn host round trip of
+ * get_link_prediction_metrics / get_node_classification_metrics (utils/metrics.py:5-34; called per batch at
+ * evaluate_models_utils.py:139-150 and per evaluation at :245-249).  predicts / labels: [n_groups, group_size] float32
+ * (labels 0.0 / 1.0, as the reference builds them with ones_like / zeros_like); one group = one call of the reference
+ * function.  Outputs (device, each nullable): average_precision [n_groups] (average_precision_score), roc_auc [n_groups]
+ * (roc_auc_score; NaN where it would raise), bce_loss [n_groups] (torch.nn.BCELoss, mean; evaluate_models_utils.py:145),
+ * status [n_groups] int32 (1 = only one class present: roc_auc_score raises ValueError there, and so does the wrapper).
+ * Rank counts are exact; sums are float64 in a fixed order (reproducible); agreement with scikit-learn <= 1e-12. */
+size_t dygnn_link_metrics_workspace_bytes(int64_t group_size, int64_t n_groups);
+int dygnn_link_metrics(const float* predicts, const float* labels, int64_t group_size, int64_t n_groups,
+                       double* average_precision, double* roc_auc, double* bce_loss, int32_t* status,
+                       void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,3 +189,57 @@ def grad_signature(name: str, g: np.ndarray) -> dict:
     out[f"{name}|proj"] = np.array(proj, dtype=np.float64)
     out[f"{name}|absmax"] = np.array(float(np.abs(g).max()))
     return out
+
+
+# ---- evaluation metrics (reference utils/metrics.py:5-34 -> scikit-learn; BCELoss of evaluate_models_utils.py:145):
+# fixture metrics.npz holds, per case, the reference's average_precision / roc_auc and torch's BCELoss (mean).
+METRIC_CASES = {
+    # name -> (n_pos, n_neg, kind, seed)
+    "balanced400": (200, 200, "logit", 1),          # one evaluation batch: 200 positive + 200 negative edges
+    "ties": (200, 200, "quantised", 2),             # scores rounded to multiples of 0.05: large tie groups across classes
+    "perfect": (50, 70, "separated", 3),
+    "inverse": (50, 70, "inverted", 4),
+    "constant": (30, 30, "constant", 5),            # one tie group: AUC 0.5, AP = prevalence
+    "odd37": (5, 32, "logit", 6),
+    "saturated": (40, 40, "saturated", 7),          # exact 0.0 / 1.0 scores: BCELoss clamps its logs at -100
+    "rare_big": (200, 19800, "logit", 8),           # node-classification shape: one call over a whole split
+}
+
+
+def build_metric_case(name: str):
+    """-> (predicts float32 [n], labels float32 [n]) in the reference's layout: positives first (evaluate_models_utils.py:142-143)"""
+    n_pos, n_neg, kind, seed = METRIC_CASES[name]
+    rs = np.random.RandomState(1000 + seed)
+    y = np.concatenate([np.ones(n_pos), np.zeros(n_neg)]).astype(np.float32)
+    z = rs.standard_normal(n_pos + n_neg) + 1.2 * y
+    p = 1.0 / (1.0 + np.exp(-z))
+    if kind == "quantised":
+        p = np.round(p * 20) / 20
+    elif kind == "separated":
+        p = np.where(y > 0, 0.6 + 0.4 * rs.random_sample(len(y)), 0.4 * rs.random_sample(len(y)))
+    elif kind == "inverted":
+        p = np.where(y > 0, 0.4 * rs.random_sample(len(y)), 0.6 + 0.4 * rs.random_sample(len(y)))
+    elif kind == "constant":
+        p = np.full(len(y), 0.25)
+    elif kind == "saturated":
+        p = np.clip(np.round(p * 4) / 4, 0.0, 1.0)
+        p[:3] = 0.0          # positives scored exactly 0
+        p[-3:] = 1.0         # negatives scored exactly 1
+    return p.astype(np.float32), y
+
+
+# ---- evaluation loop (reference evaluate_models_utils.py:18-153 run on the last EVAL_FRACTION of a graph, 'random'
+# negatives from a NegativeEdgeSampler(seed=EVAL_NEG_SEED) over the full graph): fixtures eval_<model>.npz hold the
+# per-batch losses, metrics and the sampler's negative destinations.
+EVAL_CASES = {
+    "eval_dygformer": dict(model="DyGFormer", graph="bip_p2_l64", batch=40),
+    "eval_tgat": dict(model="TGAT", graph="tgat_bip_l2_k20", batch=40),
+    "eval_tgn": dict(model="TGN", graph="tgn_bip_l1_k10", batch=40),
+}
+EVAL_FRACTION = 0.3
+EVAL_NEG_SEED = 0
+
+
+def eval_indices(num_interactions: int):
+    first = int(num_interactions * (1 - EVAL_FRACTION))
+    return first, num_interactions

@@ -1,0 +1,122 @@
+"""The evaluation loop (reference evaluate_models_utils.py:18-153) and NegativeEdgeSampler 'random' (utils/utils.py:378-390)
+against fixtures produced by running the reference loop itself (oracle/make_golden.py run_eval_case).
+Negatives: bit-exact (RandomState replay).  Losses: 1e-5 absolute (BCELoss over float32 scores that agree to ~1e-6).
+AP / AUC: the scores of these random-weight models sit within ~1e-2 of 0.5, so a 1e-6 score difference can swap one
+positive/negative pair; one swap moves AUC by 1/(40*40) and AP by up to ~1/40, hence the 2e-3 / 1e-2 bands."""
+import numpy as np
+import pytest
+
+from tests import golden_cases as gc
+
+
+def _neg_sampler(d):
+    from dyglib_amd import NegativeEdgeSampler
+    return NegativeEdgeSampler(src_node_ids=d.src_node_ids, dst_node_ids=d.dst_node_ids, seed=gc.EVAL_NEG_SEED)
+
+
+@pytest.mark.parametrize("name", list(gc.EVAL_CASES))
+def test_negative_edge_sampler_replays_reference_draws(name):
+    r = gc.EVAL_CASES[name]
+    g = gc.load_golden(name)
+    d = gc.build_case(gc.TGAT_CASES[r["graph"]]["graph"] if r["model"] == "TGAT" else gc.TGN_CASES[r["graph"]]["graph"] if r["model"] == "TGN" else r["graph"])["data"]
+    first, last = gc.eval_indices(d.num_interactions)
+    neg = _neg_sampler(d)
+    neg.sample(size=7)                      # disturb, then reset like evaluate_models_utils.py:36
+    neg.reset_random_state()
+    draws = []
+    for i in range(0, last - first, r["batch"]):
+        s, dd = neg.sample(size=min(r["batch"], last - first - i))
+        assert s.dtype == d.src_node_ids.dtype and np.isin(s, d.src_node_ids).all()
+        draws.append(dd)
+    assert np.array_equal(np.concatenate(draws), g["neg_dst"])
+    assert np.array_equal(neg.random_state.randint(0, 10, 1), g["neg_src_first"])
+
+
+def test_negative_edge_sampler_strategies():
+    from dyglib_amd import NegativeEdgeSampler
+    a = np.arange(1, 6)
+    with pytest.raises(ValueError):
+        NegativeEdgeSampler(a, a, negative_sample_strategy="nope", seed=0)
+    with pytest.raises(NotImplementedError):
+        NegativeEdgeSampler(a, a, negative_sample_strategy="historical", seed=0)
+    s, d = NegativeEdgeSampler(a, a).sample(3)          # unseeded: global numpy state (utils/utils.py:384-386)
+    assert len(s) == len(d) == 3
+
+
+def test_idx_data_loader_keeps_last_batch():
+    from dyglib_amd import get_idx_data_loader
+    b = [x.tolist() for x in get_idx_data_loader(list(range(10)), 4, False)]
+    assert b == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
+
+
+def _build(name, dev):
+    import torch
+    from dyglib_amd import DyGFormer, TGAT, MemoryModel, MergeLayer, get_neighbor_sampler
+    r = gc.EVAL_CASES[name]
+    if r["model"] == "DyGFormer":
+        c = gc.build_case(r["graph"]); cfg = c["cfg"]
+    elif r["model"] == "TGAT":
+        c = gc.build_tgat_case(r["graph"]); cfg = c["tgat_cfg"]
+    else:
+        c = gc.build_tgn_case(r["graph"]); cfg = c["tgn_cfg"]
+    d = c["data"]
+    sampler = get_neighbor_sampler(d, "recent", seed=1, device=dev)
+    if r["model"] == "DyGFormer":
+        bb = DyGFormer(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"], channel_embedding_dim=cfg["channel_embedding_dim"],
+                       patch_size=cfg["patch_size"], num_layers=cfg["num_layers"], num_heads=cfg["num_heads"], dropout=0.1,
+                       max_input_sequence_length=cfg["max_input_sequence_length"], device=dev)
+        bb.load_state_dict({k: torch.from_numpy(v) for k, v in c["params"].items()})
+    elif r["model"] == "TGAT":
+        bb = TGAT(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"], num_layers=cfg["num_layers"], num_heads=cfg["num_heads"],
+                  dropout=0.1, device=dev)
+        bb.load_state_dict({k: torch.from_numpy(v) for k, v in c["tgat_params"].items()})
+    else:
+        bb = MemoryModel(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"], model_name="TGN", num_layers=cfg["num_layers"],
+                         num_heads=cfg["num_heads"], dropout=0.1, device=dev)
+        sd = bb.state_dict(); sd.update({k: torch.from_numpy(v) for k, v in c["tgn_params"].items()}); bb.load_state_dict(sd)
+    merge = MergeLayer(172, 172, 172, 1)
+    merge.load_state_dict({k: torch.from_numpy(v) for k, v in c["mparams"].items()})
+    model = torch.nn.Sequential(bb, merge).to(dev)
+    if r["model"] == "TGN":
+        model[0].memory_bank.__init_memory_bank__()
+    return r, c, cfg, sampler, model
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(gc.EVAL_CASES))
+@pytest.mark.parametrize("fuse", [1, 5])
+def test_evaluation_loop_matches_reference(name, fuse):
+    import torch
+    from dyglib_amd import Data, evaluate_model_link_prediction, get_idx_data_loader
+    r, c, cfg, sampler, model = _build(name, "cuda:0")
+    g = gc.load_golden(name)
+    d = c["data"]
+    first, last = gc.eval_indices(d.num_interactions)
+    sl = slice(first, last)
+    eval_data = Data(d.src_node_ids[sl], d.dst_node_ids[sl], d.node_interact_times[sl], d.edge_ids[sl], d.labels[sl])
+    loader = get_idx_data_loader(list(range(last - first)), r["batch"], shuffle=False)
+    losses, metrics = evaluate_model_link_prediction(model_name=r["model"], model=model, neighbor_sampler=sampler, evaluate_idx_data_loader=loader,
+                                                     evaluate_neg_edge_sampler=_neg_sampler(d), evaluate_data=eval_data,
+                                                     loss_func=torch.nn.BCELoss(), num_neighbors=cfg.get("num_neighbors", 20), fuse_batches=fuse)
+    assert len(losses) == len(metrics) == len(g["losses"]) and all(isinstance(x, float) for x in losses)
+    assert np.abs(np.array(losses) - g["losses"]).max() <= 1e-5
+    assert np.abs(np.array([m["roc_auc"] for m in metrics]) - g["roc_auc"]).max() <= 2e-3
+    assert np.abs(np.array([m["average_precision"] for m in metrics]) - g["average_precision"]).max() <= 1e-2
+
+
+@pytest.mark.gpu
+def test_evaluation_loop_other_loss_function_and_bad_model_name():
+    import torch
+    from dyglib_amd import Data, evaluate_model_link_prediction, get_idx_data_loader
+    r, c, cfg, sampler, model = _build("eval_dygformer", "cuda:0")
+    d = c["data"]
+    first, last = gc.eval_indices(d.num_interactions)
+    sl = slice(first, first + 90)
+    eval_data = Data(d.src_node_ids[sl], d.dst_node_ids[sl], d.node_interact_times[sl], d.edge_ids[sl], d.labels[sl])
+    kw = dict(model=model, neighbor_sampler=sampler, evaluate_neg_edge_sampler=_neg_sampler(d), evaluate_data=eval_data)
+    a, _ = evaluate_model_link_prediction("DyGFormer", evaluate_idx_data_loader=get_idx_data_loader(list(range(90)), 40, False), loss_func=torch.nn.BCELoss(), **kw)
+    b, _ = evaluate_model_link_prediction("DyGFormer", evaluate_idx_data_loader=get_idx_data_loader(list(range(90)), 40, False),
+                                          loss_func=torch.nn.BCELoss(reduction="sum"), **kw)
+    assert len(a) == 3 and np.allclose(np.array(b) / np.array([80, 80, 20]), a, rtol=1e-5)
+    with pytest.raises(ValueError):
+        evaluate_model_link_prediction("JODIE", evaluate_idx_data_loader=[], loss_func=torch.nn.BCELoss(), **kw)
