@@ -26,7 +26,8 @@ CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-W
             "-ffp-contract=off"]   # contractions are written explicitly (fmaf) where the oracle has them
 
 
-VARIANTS = {"": [], "stamps": ["-DDYGNN_STAMPS=1"], "nogelu": ["-DDYGNN_STAMPS=1", "-DDYGNN_ABLATE_GELU=1"], "noload": ["-DDYGNN_STAMPS=1", "-DDYGNN_ABLATE_NOLOAD=1"]}
+VARIANTS = {"": [], "stamps": ["-DDYGNN_STAMPS=1"], "nogelu": ["-DDYGNN_STAMPS=1", "-DDYGNN_ABLATE_GELU=1"], "noload": ["-DDYGNN_STAMPS=1", "-DDYGNN_ABLATE_NOLOAD=1"],
+            "tgatnocos": ["-DDYGNN_ABLATE_TGAT_COS=1"], "tgatnogather": ["-DDYGNN_ABLATE_TGAT_GATHER=1"]}
 
 
 def lib_path(variant: str = "") -> str:

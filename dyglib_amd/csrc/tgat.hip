@@ -236,8 +236,12 @@ __global__ __launch_bounds__(256) void k_tgat_attn_lin(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < KCACHE; ++j) {
             const int64_t r = i * k + (j < k ? j : 0);
+#if defined(DYGNN_ABLATE_TGAT_GATHER)      // diagnostic build only: every gather hits row 0
+            const int64_t nrow = 0, erow = 0;
+#else
             const int64_t nrow = h_lower ? n + r : (int64_t)lower_ids[n + r];
             const int64_t erow = nbr_eid[r];
+#endif
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) xs[j][ps] = *reinterpret_cast<const f4*>(bp[ps] + (cls[ps] == 0 ? nrow : erow) * st[ps]);
         }
@@ -252,6 +256,10 @@ __global__ __launch_bounds__(256) void k_tgat_attn_lin(const float* __restrict__
 #pragma unroll 1
                 for (int j = 0; j < k; ++j) {
                     const float dt = nbr_dt[i * k + j];
+#if defined(DYGNN_ABLATE_TGAT_COS)         // diagnostic build only
+                    *reinterpret_cast<f4*>(tf + j * Ft + f) = f4{dt, w.x, b.y, w.z};
+                    continue;
+#endif
                     *reinterpret_cast<f4*>(tf + j * Ft + f) = f4{cos_time_t(fmaf(dt, w.x, b.x)), cos_time_t(fmaf(dt, w.y, b.y)), cos_time_t(fmaf(dt, w.z, b.z)),
                                                                 cos_time_t(fmaf(dt, w.w, b.w))};
                 }
@@ -336,6 +344,117 @@ __global__ __launch_bounds__(256) void k_tgat_attn_lin(const float* __restrict__
         f4* zo = reinterpret_cast<f4*>(z + ((size_t)i * H + h) * Dkv);
         if (v0) zo[x0] = za;
         if (v1) zo[x1] = zb;
+    }
+}
+
+// The same attention with TWO waves per node (k <= KC, H <= 2, Dkv <= 512): wave `hf` of a pair owns the float4 columns
+// 2*lane + hf of the input rows, so a lane keeps KC float4 (80 VGPRs at k = 20) instead of 2*KC and four to five waves fit
+// on a SIMD where the one-wave form (255 VGPRs + spills around the libm call) fitted one; the kernel is bound by gather
+// latency, so occupancy is what pays.  Phases: (A) the pair's cosines, spread over the lanes, into LDS -- BEFORE any
+// gather is in flight, so the out-of-line libm fallback of cos_time_t has nothing live to spill; (B) all k gathers back to
+// back; (C) partial scores per half -> LDS -> workgroup barrier -> both waves run the same softmax on lanes (h, j);
+// (D) weighted sum of the cached rows.  Workgroup = 2 nodes.
+template <int KC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tgat_attn_pair(const float* __restrict__ qk, const float* __restrict__ h_lower, const float* __restrict__ node_feat,
+                                                          const float* __restrict__ edge_feat, const int32_t* __restrict__ lower_ids,
+                                                          const int32_t* __restrict__ nbr_eid, const float* __restrict__ nbr_dt, const float* __restrict__ tw,
+                                                          const float* __restrict__ tb, int64_t n, int k, int Fn, int Fe, int Ft, int H, float scale,
+                                                          float* __restrict__ z) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hf = wave & 1, slot = wave >> 1;
+    int64_t i = (int64_t)blockIdx.x * 2 + slot;
+    const bool live = i < n;
+    if (!live) i = n - 1;                                   // keeps the barrier uniform; nothing is written
+    const int Dkv = Fn + Fe + Ft, D4 = Dkv >> 2, T0 = (Fn + Fe) >> 2, NT4 = Ft >> 2;
+    const int par = (hf - T0) & 1;                          // parity, inside the time block, of the time columns this half owns
+    const int ntc = (NT4 - par + 1) >> 1;                   // how many of them
+    const int TW = 4 * ((NT4 + 1) >> 1);                    // floats per row of the time staging area
+    float* part = reinterpret_cast<float*>(smem);                                   // [2 slots][2 halves][H][KC]
+    float* tf = part + 4 * H * KC + (size_t)wave * KC * TW;                         // [4 waves][KC][TW]
+    float* pw = part + 4 * H * KC + (size_t)4 * KC * TW + (size_t)wave * H * KC;    // [4 waves][H][KC]
+    const int64_t r0 = i * k;
+    // (A) time encodings of this half's columns for all k rows
+    if (lane < 4 * ntc) {
+        const int f = 4 * (2 * (lane >> 2) + par) + (lane & 3);
+        const float w = tw[f], b = tb[f];
+#pragma unroll 1
+        for (int j = 0; j < k; ++j) tf[j * TW + lane] = cos_time_t(fmaf(nbr_dt[r0 + j], w, b));
+    }
+    // (B) gathers
+    const int col = 2 * lane + hf, kk = 4 * col;
+    const bool vcol = col < D4;
+    const int cls = !vcol ? 3 : kk < Fn ? 0 : kk < Fn + Fe ? 1 : 2;
+    const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+    f4 xs[KC];
+    if (cls <= 1) {
+        const float* bp = cls == 0 ? (h_lower ? h_lower : node_feat) + kk : edge_feat + (kk - Fn);
+        const size_t st = cls == 0 ? (size_t)Fn : (size_t)Fe;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const int64_t r = r0 + (j < k ? j : 0);
+            const int64_t nrow = h_lower ? n + r : (int64_t)lower_ids[n + r];
+            const int64_t erow = nbr_eid[r];
+            xs[j] = *reinterpret_cast<const f4*>(bp + (cls == 0 ? nrow : erow) * st);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < KC; ++j) xs[j] = zero;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (cls == 2) {
+        const int lt = (col - T0) >> 1;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) xs[j] = *reinterpret_cast<const f4*>(tf + (j < k ? j : 0) * TW + 4 * lt);
+    }
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+        if (j >= k) xs[j] = zero;
+    // (C) partial scores of this half, all (row, head) reductions pipelined
+    auto dot4 = [](const f4 a, const f4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); };
+    for (int h = 0; h < H; ++h) {
+        const f4 q = vcol ? *reinterpret_cast<const f4*>(qk + ((size_t)i * H + h) * Dkv + kk) : zero;
+        float sc[KC];
+#pragma unroll
+        for (int j = 0; j < KC; ++j) sc[j] = dot4(q, xs[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int j = 0; j < KC; ++j) sc[j] += __shfl_xor(sc[j], o, 64);
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+            if (lane == j) part[((slot * 2 + hf) * H + h) * KC + j] = sc[j];
+    }
+    __syncthreads();
+    {   // softmax over the k neighbours: lane = 32 * head + row (modules.py:173 scale, :176-184 mask)
+        const int h = lane >> 5, j = lane & 31;
+        const bool on = h < H && j < k;
+        float s = -INFINITY;
+        if (on) {
+            s = (part[((slot * 2 + 0) * H + h) * KC + j] + part[((slot * 2 + 1) * H + h) * KC + j]) * scale;
+            if (lower_ids[n + r0 + j] == 0) s = -1e10f;
+        }
+        float mx = s;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float e = on ? expf(s - mx) : 0.f;
+        float sum = e;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (on) pw[h * KC + j] = e * (1.0f / sum);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // (D) z_ih = sum_j p_ijh x_ij for this half's columns
+    for (int h = 0; h < H; ++h) {
+        f4 za = zero;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {                 // no early exit: a break keeps xs[] from being promoted to registers
+            const float p = j < k ? pw[h * KC + j] : 0.f;
+            za.x = fmaf(p, xs[j].x, za.x); za.y = fmaf(p, xs[j].y, za.y); za.z = fmaf(p, xs[j].z, za.z); za.w = fmaf(p, xs[j].w, za.w);
+        }
+        if (vcol && live) *reinterpret_cast<f4*>(z + ((size_t)i * H + h) * Dkv + kk) = za;
     }
 }
 
@@ -511,7 +630,12 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
                                0, (int64_t)p.hd * p.Dkv, 0, p.Dkv)) return rc;
         const dim3 grid((unsigned)ceil_div(n, 4));
         const size_t lds = (size_t)4 * p.H * p.k * sizeof(float);
-        if (p.k <= 20)
+        if (p.k <= 20 && p.H <= 2 && p.Dkv <= 512) {
+            const int TW = 4 * ((p.Ft / 4 + 1) / 2);
+            const size_t lds2 = ((size_t)8 * p.H * 20 + (size_t)4 * 20 * TW) * sizeof(float);
+            hipLaunchKernelGGL((k_tgat_attn_pair<20>), dim3((unsigned)ceil_div(n, 2)), dim3(256), lds2, s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]),
+                               F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z));
+        } else if (p.k <= 20)
             hipLaunchKernelGGL((k_tgat_attn_lin<20>), grid, dim3(256), lds + (size_t)4 * 20 * p.Ft * sizeof(float), s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]), F32(p.dt[l]),
                                w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z));
         else

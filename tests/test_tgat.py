@@ -100,3 +100,23 @@ def test_hip_reddit_shape_batch_against_oracle():
         gs, gd = m.compute_src_dst_node_temporal_embeddings(src, dst, t, num_neighbors=20)
     close(gs.cpu().numpy(), os_.numpy(), "src")
     close(gd.cpu().numpy(), od.numpy(), "dst")
+
+
+@pytest.mark.gpu
+def test_hip_rows_do_not_depend_on_the_batch_they_are_in():
+    """TGAT has no batch-dependent padding (fixed k): eight 200-edge evaluation steps in one call give the rows of the
+    eight separate calls (what tools/bench_tgat.py --fuse-steps and evaluate.py rely on)."""
+    from dyglib_amd import TGAT, get_neighbor_sampler
+    data, nf, ef = syn.make_bipartite_graph(500, 60, 30000, seed=31)
+    sampler = get_neighbor_sampler(data, "recent", seed=1, device="cuda:0")
+    m = TGAT(nf, ef, sampler, 100, num_layers=2, num_heads=2, dropout=0.1, device="cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_tgat_params(9).items()})
+    m = m.to("cuda:0").eval()
+    idx = np.arange(data.num_interactions - 1600, data.num_interactions)
+    src, dst, t = data.src_node_ids[idx], data.dst_node_ids[idx], data.node_interact_times[idx]
+    with torch.no_grad():
+        fs, fd = m.compute_src_dst_node_temporal_embeddings(src, dst, t, num_neighbors=20)
+        for j in range(8):
+            sl = slice(200 * j, 200 * (j + 1))
+            ss, sd = m.compute_src_dst_node_temporal_embeddings(src[sl], dst[sl], t[sl], num_neighbors=20)
+            assert torch.equal(fs[sl], ss) and torch.equal(fd[sl], sd), j

@@ -60,7 +60,7 @@ torch.cuda.synchronize()
 sec = (time.perf_counter() - t0) / steps
 
 # CPU baseline: the same step through the oracle's autograd (torch CPU, 16 threads), 2 steps
-cpu = bench.cpu_baseline_train(data, nf, ef, params, mparams, batch, P, L, 2, B)
+cpu = bench.cpu_baseline_train(data, nf, ef, params, mparams, batch, P, L, 2, B) if os.environ.get("CPU_STEPS", "2") != "0" else None
 print(json.dumps({"metric": "edges/sec (link-prediction TRAIN step: fwd pos+neg, bwd, Adam) DyGFormer Wikipedia-shaped", "value": round(B / sec, 1),
                   "unit": "edges/s", "ms_per_step": round(sec * 1e3, 3), "steps": steps, "dtype": "f32", "dropout": 0.1, "final_loss": round(float(loss.detach()), 4),
                   "cpu_baseline": cpu}))
