@@ -87,17 +87,26 @@ def evaluate_model_link_prediction(model_name: str, model: nn.Module, neighbor_s
             tms = np.stack([g[2] for g in groups_pos] + [g[2] for g in groups_neg])
             a, b = backbone.compute_src_dst_node_temporal_embeddings_many(src, dst, tms)
             prob = merge.link_probabilities(a.reshape(2 * n * B, -1), b.reshape(2 * n * B, -1)).reshape(2, n, B)
-        else:
+        elif model_name == "TGAT" and neighbor_sampler.sample_neighbor_strategy == "recent":
+            # rows do not depend on the batch they are in (fixed k, stateless sampling): the n batches are one call on n*B edges
+            cat = lambda gs, c: np.concatenate([g[c] for g in gs])
+            pe = backbone.compute_src_dst_node_temporal_embeddings(cat(groups_pos, 0), cat(groups_pos, 1), cat(groups_pos, 2), num_neighbors=num_neighbors)
+            ne = backbone.compute_src_dst_node_temporal_embeddings(cat(groups_neg, 0), cat(groups_neg, 1), cat(groups_neg, 2), num_neighbors=num_neighbors)
+            prob = torch.stack([merge.link_probabilities(*pe).reshape(n, B), merge.link_probabilities(*ne).reshape(n, B)])
+        elif model_name == "TGAT":      # random strategies consume the sampler's RandomState call by call: keep the reference's call order
             probs = []
             for gp, gn in zip(groups_pos, groups_neg):
-                if model_name == "TGAT":
-                    pe = backbone.compute_src_dst_node_temporal_embeddings(gp[0], gp[1], gp[2], num_neighbors=num_neighbors)
-                    ne = backbone.compute_src_dst_node_temporal_embeddings(gn[0], gn[1], gn[2], num_neighbors=num_neighbors)
-                else:       # TGN: negatives first, they must not see the memories this batch's positives write (:85-107)
-                    ne = backbone.compute_src_dst_node_temporal_embeddings(gn[0], gn[1], gn[2], edge_ids=None, edges_are_positive=False,
-                                                                           num_neighbors=num_neighbors)
-                    pe = backbone.compute_src_dst_node_temporal_embeddings(gp[0], gp[1], gp[2], edge_ids=gp[3], edges_are_positive=True,
-                                                                           num_neighbors=num_neighbors)
+                pe = backbone.compute_src_dst_node_temporal_embeddings(gp[0], gp[1], gp[2], num_neighbors=num_neighbors)
+                ne = backbone.compute_src_dst_node_temporal_embeddings(gn[0], gn[1], gn[2], num_neighbors=num_neighbors)
+                probs.append(torch.stack([merge.link_probabilities(*pe), merge.link_probabilities(*ne)]))
+            prob = torch.stack(probs, dim=1)
+        else:       # TGN: strictly sequential; negatives first, they must not see the memories this batch's positives write (:85-107)
+            probs = []
+            for gp, gn in zip(groups_pos, groups_neg):
+                ne = backbone.compute_src_dst_node_temporal_embeddings(gn[0], gn[1], gn[2], edge_ids=None, edges_are_positive=False,
+                                                                       num_neighbors=num_neighbors)
+                pe = backbone.compute_src_dst_node_temporal_embeddings(gp[0], gp[1], gp[2], edge_ids=gp[3], edges_are_positive=True,
+                                                                       num_neighbors=num_neighbors)
                 probs.append(torch.stack([merge.link_probabilities(*pe), merge.link_probabilities(*ne)]))
             prob = torch.stack(probs, dim=1)
         predicts = torch.cat([prob[0], prob[1]], dim=1)                                     # :142
