@@ -11,6 +11,8 @@ from dyglib_amd import MemoryModel, MergeLayer, get_neighbor_sampler, synthetic 
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=100); ap.add_argument("--warmup", type=int, default=10); ap.add_argument("--cpu-steps", type=int, default=10)
+ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per step instead of issuing its ~50 launches (measured: no gain, "
+                "257 k vs 262 k edges/s -- the step is bound by the GPU-side latency of ~50 dependent small kernels, not by the host)")
 args = ap.parse_args()
 dev, B, K = "cuda:0", 200, 10
 data, nf, ef = syn.make_bipartite_graph(7047, 97, 411749, seed=0, edge_feat_kind="sparse4")
@@ -26,18 +28,24 @@ host = [(data.src_node_ids[i * B:(i + 1) * B], data.dst_node_ids[i * B:(i + 1) *
          data.node_interact_times[i * B:(i + 1) * B], data.edge_ids[i * B:(i + 1) * B]) for i in range(n)]
 batches = [tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in b) for b in host]
 def step(i):
-    s, d, ng, t, e = batches[i]
+    return step_on(*batches[i])
+def step_on(s, d, ng, t, e):
     with torch.no_grad():
         a, b_ = model.compute_src_dst_node_temporal_embeddings(s, ng, t, edge_ids=None, edges_are_positive=False, num_neighbors=K)
         c, f = model.compute_src_dst_node_temporal_embeddings(s, d, t, edge_ids=e, edges_are_positive=True, num_neighbors=K)
         return merge.link_probabilities(c, f), merge.link_probabilities(a, b_)
 model.memory_bank.__init_memory_bank__()
 for i in range(args.warmup): step(i)
+run = step
+if args.graph:                       # same kernels, same arguments: one hipGraph launch per step instead of ~50 kernel launches
+    from dyglib_amd.graphs import GraphedStep
+    graphed = GraphedStep(lambda s, d, ng, t, e: step_on(s, d, ng, t, e), batches[args.warmup])
+    run = lambda i: graphed(*batches[i])
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for i in range(args.steps): step(args.warmup + i)
+for i in range(args.steps): run(args.warmup + i)
 torch.cuda.synchronize(); el = time.perf_counter() - t0
 out = {"metric": "edges/sec (link-prediction fwd) TGN MOOC-shaped", "value": round(args.steps * B / el, 1), "unit": "edges/s", "n_gpus": 1,
-       "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "dtype": "f32", "data": "synthetic", "scaling": "replicas only",
+       "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "dtype": "f32", "data": "synthetic", "scaling": "replicas only", "hip_graph": args.graph,
        "config": {"workload": "TGN link-prediction forward, synthetic MOOC-shaped graph (7047+97 nodes, 411749 edges), k=10, 1 layer, batch=200, sequential batches"}}
 if args.cpu_steps > 0:
     import bench                                   # the CPU-baseline leg lives in bench.py (the only non-test user of oracle/)
