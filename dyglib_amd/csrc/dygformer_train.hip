@@ -239,19 +239,18 @@ int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb,
         p.beta = 0.f;
     }
     batch *= p.ksplit;
-    if (M >= 128 && N >= 48) {
+    if (M >= 48 && N >= 48) {
         const int vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && lda % 4 == 0 && sAb % 4 == 0 && sAh % 4 == 0) ? 1 : 0;
         const int vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && ldb % 4 == 0 && sBb % 4 == 0 && sBh % 4 == 0) ? 1 : 0;
-        // mid-size products (a few hundred 128-row tiles at most): 64-row tiles put 2-4 workgroups on every CU, which hides
-        // the per-k-step load latency that a single resident workgroup exposes
-        const bool small_grid = ceil_div(M, 128) * ceil_div(N, N > 64 ? 128 : 64) * batch < 512;
-        if (N > 64) {
-            if (small_grid) hipLaunchKernelGGL((k_mm_big<4, 2>), dim3((unsigned)ceil_div(M, 64), (unsigned)ceil_div(N, 128), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
-            else hipLaunchKernelGGL((k_mm_big<4, 4>), dim3((unsigned)ceil_div(M, 128), (unsigned)ceil_div(N, 128), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
-        } else {
-            if (small_grid) hipLaunchKernelGGL((k_mm_big<2, 2>), dim3((unsigned)ceil_div(M, 64), (unsigned)ceil_div(N, 64), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
-            else hipLaunchKernelGGL((k_mm_big<2, 4>), dim3((unsigned)ceil_div(M, 128), (unsigned)ceil_div(N, 64), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
-        }
+        // Tile choice, measured on the TGAT / TGN / training shapes (M = 50 .. 270,000, N = 136 .. 800, K = 136 .. 25,600 split):
+        //  * 64-row tiles always: the k-loop is latency-bound (one global -> LDS hop per 16-wide k-step), so what pays is more resident
+        //    workgroups per CU, not more MFMAs per LDS read; 128-row tiles were slower at every size (TGAT -7 %, training -5 %);
+        //  * 64-column tiles unless 128-column tiles pad clearly less (N = 272 pads to 320 instead of 384): TGN +38 %, TGAT +14 %.
+        const double w64 = (double)(ceil_div(N, 64) * 64) / N, w128 = (double)(ceil_div(N, 128) * 128) / N;
+        if (N <= 64 || w64 * 0.95 < w128)
+            hipLaunchKernelGGL((k_mm_big<2, 2>), dim3((unsigned)ceil_div(M, 64), (unsigned)ceil_div(N, 64), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
+        else
+            hipLaunchKernelGGL((k_mm_big<4, 2>), dim3((unsigned)ceil_div(M, 64), (unsigned)ceil_div(N, 128), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
         DYGNN_LAUNCH_CHECK();
         return DYGNN_OK;
     }

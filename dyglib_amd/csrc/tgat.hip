@@ -552,7 +552,7 @@ static int check_tgat(const dygnn_tgat_config* c) {
 template <bool RELU>
 static int gemm_nt(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, int ldc, hipStream_t s) {
     if (M == 0) return DYGNN_OK;
-    if (M >= 128) return train::mm(s, A, K, false, W, K, true, C, ldc, (int)M, N, K, bias, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, RELU);      // the LDS-tiled general GEMM
+    if (M >= 48) return train::mm(s, A, K, false, W, K, true, C, ldc, (int)M, N, K, bias, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, RELU);      // the LDS-tiled general GEMM
     hipLaunchKernelGGL((k_gemm_nt<RELU>), dim3((unsigned)ceil_div(M, 256), (unsigned)ceil_div(N, 64)), dim3(256), 0, s, A, W, bias, C, M, N, K, ldc);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
