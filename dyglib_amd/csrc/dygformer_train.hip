@@ -33,6 +33,7 @@ struct MM {
     int H; int64_t sAb, sAh, sBb, sBh, sCb, sCh;
     int relu;               // epilogue max(v, 0) (not combined with split-K)
     int ksplit, kchunk;     // split-K: blockIdx.z = batch * ksplit + part; part sums k in [part*kchunk, +kchunk) and adds atomically
+    float* colsum;          // transA products only: colsum[m] += sum_k op(A)[m][k] (the bias gradient next to a weight gradient), or null
 };
 
 __global__ __launch_bounds__(256) void k_mm(const MM p) {
@@ -188,9 +189,16 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
     stash(0);
     __syncthreads();
     int buf = 0;
+    static_assert(BM == 64, "the column-sum side product assumes 64-row tiles (wave w sums k rows 4w .. 4w+3 of column `lane`)");
+    const bool want_colsum = p.colsum != nullptr && blockIdx.y == 0;
+    float csum = 0.f;
     for (int k0 = kbeg; k0 < kend; k0 += 16) {
         const bool more = k0 + 16 < kend;
         if (more) fetch(k0 + 16);
+        if (want_colsum) {                        // rows beyond kend / M were stored as zeros
+            const int col = (lane + 16 * wave) & (BM - 1);
+            csum += (As[buf][4 * wave][col] + As[buf][4 * wave + 1][col]) + (As[buf][4 * wave + 2][col] + As[buf][4 * wave + 3][col]);
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             float a[WM], b[WN];
@@ -207,6 +215,7 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
         __syncthreads();
         buf ^= 1;
     }
+    if (want_colsum && m0 + lane < p.M) atomicAdd(&p.colsum[m0 + lane], csum);
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int n = n0 + 16 * WN * wx + 16 * j + c;
@@ -227,10 +236,16 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
     }
 }
 
+static int colsum(hipStream_t s, const float* A, int lda, int64_t M, int N, float* out, bool accumulate = false);
+
 int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb, bool tB, float* C, int ldc, int M, int N, int K, const float* bias, float alpha,
-       float beta, int batch, int H, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, bool relu, bool c_is_zero) {
+       float beta, int batch, int H, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, bool relu, bool c_is_zero, float* colsum_out) {
     if (M <= 0 || N <= 0 || batch <= 0) return DYGNN_OK;
-    MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh, relu ? 1 : 0, 1, K};
+    MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh, relu ? 1 : 0, 1, K, nullptr};
+    if (colsum_out) {                 // rides along inside the 64-row-tile kernel; anything else gets the stand-alone reduction
+        if (tA && batch == 1 && M >= 48 && N >= 48) p.colsum = colsum_out;
+        else if (int rc = colsum(s, A, lda, K, M, colsum_out)) return rc;
+    }
     // weight gradients: small output, K = all rows of the call -> split K over workgroups, partial sums meet by atomicAdd
     if (batch == 1 && K >= 2048 && !relu) {
         p.kchunk = 256;
@@ -271,7 +286,7 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ A, int
     __syncthreads();
     if (r0 == 0 && n < N) atomicAdd(&out[n], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
-static int colsum(hipStream_t s, const float* A, int lda, int64_t M, int N, float* out, bool accumulate = false) {
+static int colsum(hipStream_t s, const float* A, int lda, int64_t M, int N, float* out, bool accumulate) {
     (void)accumulate;        // gradient buffers arrive zeroed (dygnn_dygformer_backward contract): every call accumulates
     hipLaunchKernelGGL(k_colsum, dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 256)), dim3(256), 0, s, A, lda, M, N, out);
     DYGNN_LAUNCH_CHECK();
@@ -330,28 +345,43 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dY, co
     extern __shared__ float part[];            // [4 waves][2][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int rr = 0; rr < 16; ++rr) {          // 64 rows per workgroup
-        const int64_t row = (int64_t)blockIdx.x * 64 + rr * 4 + wave;
-        if (row >= M) break;
-        const float mean = mean_i[row], rstd = rstd_i[row];
-        float xh[4], dy[4], s1 = 0.f, s2 = 0.f;
+    constexpr int RB = 4;                      // rows of one wave in flight together: their loads and reductions overlap
+    for (int rr = 0; rr < 16; rr += RB) {      // 64 rows per workgroup, 16 per wave
+        float xh[RB][4], dy[RB][4], s1[RB], s2[RB], rstd[RB];
+        int64_t row[RB];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = lane + 64 * q;
-            xh[q] = 0.f; dy[q] = 0.f;
-            if (k < D) {
-                xh[q] = (X[row * D + k] - mean) * rstd; dy[q] = dY[row * D + k];
-                const float gy = dy[q] * gamma[k];
-                s1 += gy; s2 = fmaf(gy, xh[q], s2);
+        for (int u = 0; u < RB; ++u) {
+            row[u] = (int64_t)blockIdx.x * 64 + (rr + u) * 4 + wave;
+            const bool on = row[u] < M;
+            const float mean = on ? mean_i[row[u]] : 0.f;
+            rstd[u] = on ? rstd_i[row[u]] : 0.f;
+            s1[u] = 0.f; s2[u] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = lane + 64 * q;
+                xh[u][q] = 0.f; dy[u][q] = 0.f;
+                if (on && k < D) {
+                    xh[u][q] = (X[row[u] * D + k] - mean) * rstd[u]; dy[u][q] = dY[row[u] * D + k];
+                    const float gy = dy[u][q] * gamma[k];
+                    s1[u] += gy; s2[u] = fmaf(gy, xh[u][q], s2[u]);
+                }
             }
         }
-        s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = lane + 64 * q;
-            if (k < D) {
-                dX[row * D + k] += rstd * (dy[q] * gamma[k] - s1 - xh[q] * s2);
-                pg[q] = fmaf(dy[q], xh[q], pg[q]); pb[q] += dy[q];
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < RB; ++u) { s1[u] += __shfl_xor(s1[u], o, 64); s2[u] += __shfl_xor(s2[u], o, 64); }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            if (row[u] >= M) continue;
+            const float m1 = s1[u] / (float)D, m2 = s2[u] / (float)D;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = lane + 64 * q;
+                if (k < D) {
+                    dX[row[u] * D + k] += rstd[u] * (dy[u][q] * gamma[k] - m1 - xh[u][q] * m2);
+                    pg[q] = fmaf(dy[u][q], xh[u][q], pg[q]); pb[q] += dy[u][q];
+                }
             }
         }
     }
@@ -467,19 +497,31 @@ __global__ __launch_bounds__(256) void k_embed_inputs(const EmbedArgs a) {
         for (int q = a.Ss; q < S; ++q) cdn += (ids[q] == v);
         if (v == 0) { cs = 0; cdn = 0; }
         c0[p] = cs; c1[p] = cdn;
-        a.ids[b * S + p] = v; a.dts[b * S + p] = dts[p]; a.c0[b * S + p] = cs; a.c1[b * S + p] = cdn;
+        if (blockIdx.y == 0) { a.ids[b * S + p] = v; a.dts[b * S + p] = dts[p]; a.c0[b * S + p] = cs; a.c1[b * S + p] = cdn; }
     }
     __syncthreads();
-    const int Kn = a.P * a.Fn, Ke = a.P * a.Fe, Kt = a.P * a.Ft, Kc = a.P * a.C, Kall = Kn + Ke + Kt + Kc;
-    for (int idx = threadIdx.x; idx < a.T * Kall; idx += 256) {
-        const int tok = idx / Kall;
-        int k = idx - tok * Kall;
+    // the patch matrices: the workgroups (b, 0 .. gridDim.y-1) of a pair share its tokens (each rebuilt the 128-position window
+    // above, which is cheap); node / edge rows move as float4
+    const int tok0 = (int)((int64_t)a.T * blockIdx.y / gridDim.y), ntok = (int)((int64_t)a.T * (blockIdx.y + 1) / gridDim.y) - tok0;
+    const int Kn = a.P * a.Fn, Ke = a.P * a.Fe, Kt = a.P * a.Ft, Kc = a.P * a.C;
+    const int Kn4 = Kn >> 2, KV = Kn4 + (Ke >> 2), KS = Kt + Kc;
+    for (int idx = threadIdx.x; idx < ntok * KV; idx += 256) {
+        const int tok = tok0 + idx / KV, k4 = idx % KV;
         const int p0 = tok < a.Ts ? tok * a.P : a.Ss + (tok - a.Ts) * a.P;
         const int64_t row = b * a.T + tok;
-        if (k < Kn) { const int pp = p0 + k / a.Fn; a.Pn[row * Kn + k] = a.node_feat[(size_t)ids[pp] * a.Fn + k % a.Fn]; continue; }
-        k -= Kn;
-        if (k < Ke) { const int pp = p0 + k / a.Fe; a.Pe[row * Ke + k] = a.edge_feat[(size_t)eids[pp] * a.Fe + k % a.Fe]; continue; }
-        k -= Ke;
+        if (k4 < Kn4) {
+            const int k = 4 * k4, pp = p0 + k / a.Fn;
+            *reinterpret_cast<f4*>(a.Pn + row * Kn + k) = *reinterpret_cast<const f4*>(a.node_feat + (size_t)ids[pp] * a.Fn + k % a.Fn);
+        } else {
+            const int k = 4 * (k4 - Kn4), pp = p0 + k / a.Fe;
+            *reinterpret_cast<f4*>(a.Pe + row * Ke + k) = *reinterpret_cast<const f4*>(a.edge_feat + (size_t)eids[pp] * a.Fe + k % a.Fe);
+        }
+    }
+    for (int idx = threadIdx.x; idx < ntok * KS; idx += 256) {
+        const int tok = tok0 + idx / KS;
+        int k = idx % KS;
+        const int p0 = tok < a.Ts ? tok * a.P : a.Ss + (tok - a.Ts) * a.P;
+        const int64_t row = b * a.T + tok;
         if (k < Kt) {
             const int pp = p0 + k / a.Ft, f = k % a.Ft;
             a.Pt[row * Kt + k] = ids[pp] == 0 ? 0.f : cosf(fmaf(dts[pp], a.time_w[f], a.time_b[f]));                 // modules.py:37, DyGFormer.py:266
@@ -707,7 +749,7 @@ extern "C" int dygnn_dygformer_train_forward(const dygnn_dygformer_config* cfg, 
     EmbedArgs ea{csr->indptr, csr->nbr, csr->eid, csr->ts, src, dst, times, reinterpret_cast<const int32_t*>(ws + p.wl.hist_len),
                  reinterpret_cast<const int64_t*>(ws + p.wl.end_pos), node_feat, edge_feat, w->time_w, w->time_b, F32(p.lut), B, Ss, Sd, Ts, T, d.P, d.L,
                  d.Fn, d.Fe, d.Ft, C, I32(p.ids), I32(p.c0), I32(p.c1), F32(p.dts), F32(p.Pn), F32(p.Pe), F32(p.Pt), F32(p.Pc)};
-    hipLaunchKernelGGL(k_embed_inputs, dim3((unsigned)B), dim3(256), (size_t)5 * S * 4, s, ea);
+    hipLaunchKernelGGL(k_embed_inputs, dim3((unsigned)B, (unsigned)(T >= 8 ? 8 : 1)), dim3(256), (size_t)5 * S * 4, s, ea);
     DYGNN_LAUNCH_CHECK();
     // projections (DyGFormer.py:148-157): X0[:, 50ch : 50ch+50] = P_ch . W_ch^T + b_ch
     const float* PW[4] = {w->proj_node_w, w->proj_edge_w, w->proj_time_w, w->proj_cooc_w};
@@ -789,20 +831,17 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
         float* dQKV = F32(p.dQKV);      // [M][3D]
         // X_{l+1} = X1 + drop(F2), F2 = Hact W2^T + b2
         EW(k_drop_bwd, M * D, dX, M * D, dr, (uint32_t)(4 * l + 3), dA);                                                       // dF2
-        if (int rc = mm(s, dA, D, true, F32(L.hact), 4 * D, false, G(Lg.ffn1_weight), 4 * D, D, 4 * D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true)) return rc;     // dW2 [D][4D]
-        if (int rc = colsum(s, dA, D, M, D, G(Lg.ffn1_bias))) return rc;
+        if (int rc = mm(s, dA, D, true, F32(L.hact), 4 * D, false, G(Lg.ffn1_weight), 4 * D, D, 4 * D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true, G(Lg.ffn1_bias))) return rc;     // dW2 [D][4D]
         if (int rc = mm(s, dA, D, false, Lw.ffn1_weight, 4 * D, false, dH, 4 * D, (int)M, 4 * D, D)) return rc;                 // dHact
         EW(k_gelu_drop_bwd, M * 4 * D, dH, F32(L.hpre), M * 4 * D, dr, (uint32_t)(4 * l + 2));                                 // dHpre
-        if (int rc = mm(s, dH, 4 * D, true, F32(L.xn1), D, false, G(Lg.ffn0_weight), D, 4 * D, D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true)) return rc;           // dW1 [4D][D]
-        if (int rc = colsum(s, dH, 4 * D, M, 4 * D, G(Lg.ffn0_bias))) return rc;
+        if (int rc = mm(s, dH, 4 * D, true, F32(L.xn1), D, false, G(Lg.ffn0_weight), D, 4 * D, D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true, G(Lg.ffn0_bias))) return rc;           // dW1 [4D][D]
         if (int rc = mm(s, dH, 4 * D, false, Lw.ffn0_weight, D, false, dBf, D, (int)M, D, 4 * D)) return rc;                    // dxn1
         hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)ceil_div(M, 64)), dim3(256), 8 * D * sizeof(float), s, dBf, F32(L.x1), F32(L.m1), F32(L.r1), Lw.norm1_weight, M, D,
                            dX, G(Lg.norm1_weight), G(Lg.norm1_bias));                                                          // dX is now dX1
         DYGNN_LAUNCH_CHECK();
         // X1 = Xin + drop(Ao), Ao = Oa Wo^T + bo
         EW(k_drop_bwd, M * D, dX, M * D, dr, (uint32_t)(4 * l + 1), dA);                                                       // dAo
-        if (int rc = mm(s, dA, D, true, F32(L.oa), D, false, G(Lg.out_proj_weight), D, D, D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true)) return rc;
-        if (int rc = colsum(s, dA, D, M, D, G(Lg.out_proj_bias))) return rc;
+        if (int rc = mm(s, dA, D, true, F32(L.oa), D, false, G(Lg.out_proj_weight), D, D, D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true, G(Lg.out_proj_bias))) return rc;
         if (int rc = mm(s, dA, D, false, Lw.out_proj_weight, D, false, dBf, D, (int)M, D, D)) return rc;                        // dOa
         // attention: Oa_bh = Pd_bh V_bh ; S_bh = scale Q_bh K_bh^T
         // dV_bh = Pd^T dOa_bh
@@ -818,8 +857,7 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
                         (int64_t)T * T, (int64_t)T * 3 * D, hd, (int64_t)T * 3 * D, hd)) return rc;
         if (int rc = mm(s, F32(L.S), T, true, F32(L.qkv), 3 * D, false, dQKV + D, 3 * D, T, hd, T, nullptr, scale, 0.f, (int)(B * H), H, (int64_t)H * T * T,
                         (int64_t)T * T, (int64_t)T * 3 * D, hd, (int64_t)T * 3 * D, hd)) return rc;
-        if (int rc = mm(s, dQKV, 3 * D, true, F32(L.xn0), D, false, G(Lg.in_proj_weight), D, 3 * D, D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true)) return rc;      // dWin [3D][D]
-        if (int rc = colsum(s, dQKV, 3 * D, M, 3 * D, G(Lg.in_proj_bias))) return rc;
+        if (int rc = mm(s, dQKV, 3 * D, true, F32(L.xn0), D, false, G(Lg.in_proj_weight), D, 3 * D, D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true, G(Lg.in_proj_bias))) return rc;      // dWin [3D][D]
         if (int rc = mm(s, dQKV, 3 * D, false, Lw.in_proj_weight, D, false, dA, D, (int)M, D, 3 * D)) return rc;                // dxn0
         hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)ceil_div(M, 64)), dim3(256), 8 * D * sizeof(float), s, dA, F32(p.X[l]), F32(L.m0), F32(L.r0), Lw.norm0_weight, M, D,
                            dX, G(Lg.norm0_weight), G(Lg.norm0_bias));                                                          // dX is now dX_l
@@ -832,8 +870,7 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
     const size_t PM[4] = {p.Pn, p.Pe, p.Pt, p.Pc};
     const int PK[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * C};
     for (int ch = 0; ch < 4; ++ch) {
-        if (int rc = mm(s, dX + ch * C, D, true, F32(PM[ch]), PK[ch], false, GW[ch], PK[ch], C, PK[ch], (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true)) return rc;     // dW_ch [C][K]
-        if (int rc = colsum(s, dX + ch * C, D, M, C, GB[ch])) return rc;
+        if (int rc = mm(s, dX + ch * C, D, true, F32(PM[ch]), PK[ch], false, GW[ch], PK[ch], C, PK[ch], (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true, GB[ch])) return rc;     // dW_ch [C][K]
     }
     // time encoder
     if (int rc = mm(s, dX + 2 * C, D, false, PW[2], PK[2], false, F32(p.dPt), PK[2], (int)M, PK[2], C)) return rc;
