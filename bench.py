@@ -184,6 +184,8 @@ def main():
     streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 1 else [torch.cuda.current_stream(dev)]
     # per-stream accumulators [sum AUC, sum mean-prob gap, steps] (no cross-stream read-modify-write)
     metric_accs = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in streams]
+    from dyglib_amd import link_prediction_metrics_device
+    labels_full = torch.cat([torch.ones(F, B), torch.zeros(F, B)], dim=1).to(dev)          # evaluate_models_utils.py:143
 
     def launch(first_step: int, nsteps: int, li: int, ev=None):
         """steps first_step .. first_step+nsteps-1 of this rank as ONE hot-path launch (2*nsteps groups)."""
@@ -201,10 +203,11 @@ def main():
                 ev[1].record(st)
             prob = merge.link_probabilities(s.reshape(-1, s.shape[-1]), d.reshape(-1, d.shape[-1])).reshape(2, nsteps, B)
             pos, negp = prob[0], prob[1]
-            # per-step ranking metric on device (AUC = P(pos > neg) over the BxB pairs), reduced over RCCL
-            gt = (pos[:, :, None] > negp[:, None, :]).double().mean(dim=(1, 2))
-            eq = (pos[:, :, None] == negp[:, None, :]).double().mean(dim=(1, 2))
-            m = torch.stack([(gt + 0.5 * eq).sum(), (pos.mean(dim=1) - negp.mean(dim=1)).double().sum(),
+            # per-step ROC AUC on the device (dygnn_link_metrics: evaluate_models_utils.py:139-150 without the host round trip), reduced over RCCL
+            predicts = torch.cat([pos, negp], dim=1)
+            labels = labels_full[:nsteps]
+            _, auc, _, _ = link_prediction_metrics_device(predicts, labels)
+            m = torch.stack([auc.sum(), (pos.mean(dim=1) - negp.mean(dim=1)).double().sum(),
                              torch.full((), float(nsteps), dtype=torch.float64, device=dev)])
             D.reduce_metric_sums(m)                              # RCCL all-reduce of 3 float64 when N > 1
             metric_accs[li % len(streams)].add_(m)
