@@ -170,13 +170,7 @@ class DyGFormer(nn.Module):
             raise AssertionError("src_node_ids, dst_node_ids and node_interact_times must have the same length")
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if (self.training or needs_grad) and B > 0 and _taps is None:
-            for p in self.parameters():
-                if p.dtype != torch.float32 or not p.is_contiguous():
-                    raise _capi.DygnnError("parameters must be contiguous float32")
-            p_drop = float(self.dropout) if self.training else 0.0
-            seed = getattr(self, "_fixed_dropout_seed", None)             # tests pin the masks; normally torch.manual_seed governs them
-            if seed is None:
-                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            p_drop, seed = self._dropout_and_seed()
             seq_lens = self._seq_lens_side_stream(src_node_ids, dst_node_ids, node_interact_times, src, dst, tms, dev)
             return _TrainFunction.apply(self, src, dst, tms, p_drop, seed, seq_lens, *self.parameters())
         out_src = torch.empty((B, self.node_feat_dim), dtype=torch.float32, device=dev)
@@ -212,8 +206,53 @@ class DyGFormer(nn.Module):
         if src.dim() != 2 or src.shape != dst.shape or src.shape != tms.shape:
             raise AssertionError("expected three [N, B] arrays of equal shape")
         N, B = src.shape
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if (self.training or needs_grad) and N * B > 0:
+            # training: the dense pass has ONE pair of padded lengths.  When every call of the set pads to the same lengths (the
+            # usual case: some window of each call is full) the N calls are one pass over N*B pairs -- pairs never interact, so each
+            # row equals the row of its own call and the parameter gradients are the sums of the per-call gradients, with half the
+            # launches and no gradient-accumulation kernels; otherwise call by call.  Dropout masks are drawn per pass.
+            lens = self._seq_lens_groups(src, dst, tms, dev)
+            if all(l == lens[0] for l in lens):
+                p_drop, seed = self._dropout_and_seed()
+                a, b = _TrainFunction.apply(self, src.reshape(-1), dst.reshape(-1), tms.reshape(-1), p_drop, seed, lens[0], *self.parameters())
+                return a.reshape(N, B, -1), b.reshape(N, B, -1)
+            outs = [self.compute_src_dst_node_temporal_embeddings(src[i], dst[i], tms[i]) for i in range(N)]
+            return torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs])
         a, b = self.compute_src_dst_node_temporal_embeddings(src.reshape(-1), dst.reshape(-1), tms.reshape(-1), _group_size=B)
         return a.reshape(N, B, -1), b.reshape(N, B, -1)
+
+    def _dropout_and_seed(self):
+        for p in self.parameters():
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise _capi.DygnnError("parameters must be contiguous float32")
+        seed = getattr(self, "_fixed_dropout_seed", None)             # tests pin the masks; normally torch.manual_seed governs them
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return (float(self.dropout) if self.training else 0.0), seed
+
+    def _seq_lens_groups(self, src: torch.Tensor, dst: torch.Tensor, tms: torch.Tensor, dev):
+        """(S_src, S_dst) of each of the N calls in [N, B] device inputs, on the side stream (one synchronisation of it)."""
+        side = getattr(self, "_side", None)
+        if side is None or side.device != dev:
+            side = self._side = torch.cuda.Stream(dev)
+        L, P = self.max_input_sequence_length, self.patch_size
+        N, B = src.shape
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            hist = torch.empty(B, dtype=torch.int32, device=dev)
+            end = torch.empty(B, dtype=torch.int64, device=dev)
+            maxw = torch.zeros(N, 2, dtype=torch.int32, device=dev)
+            csr = self.neighbor_sampler.csr.on_device(dev)
+            for i in range(N):
+                for half, nodes in enumerate((src[i], dst[i])):
+                    _capi.check(self._lib.dygnn_window_lengths(csr, nodes.data_ptr(), tms[i].data_ptr(), B, L, hist.data_ptr(), end.data_ptr(),
+                                                               maxw[i, half:half + 1].data_ptr(), side.cuda_stream))
+            m = maxw.cpu()                               # synchronises the side stream only
+        src.record_stream(side); dst.record_stream(side); tms.record_stream(side)
+        return [tuple((int(v) + 1) + (P - (int(v) + 1) % P) % P for v in row) for row in m.tolist()]
 
     def _seq_lens_side_stream(self, src_in, dst_in, t_in, src, dst, tms, dev):
         """(S_src, S_dst) of this call, computed on a side stream so that the training forward does not have to synchronise the main

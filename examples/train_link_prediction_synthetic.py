@@ -90,8 +90,9 @@ def main():
             sl = slice(i * args.batch, (i + 1) * args.batch)
             src, dst, t = train.src_node_ids[sl], train.dst_node_ids[sl], train.node_interact_times[sl]
             neg = rs.choice(items, size=len(src))
-            ps, pd = model.compute_src_dst_node_temporal_embeddings(src, dst, t)
-            ns, nd = model.compute_src_dst_node_temporal_embeddings(src, neg, t)
+            # the positive and the negative call of the step (train_link_prediction.py:229-239) as one set: one dense pass when they pad alike
+            s2, d2 = model.compute_src_dst_node_temporal_embeddings_many(np.stack([src, src]), np.stack([dst, neg]), np.stack([t, t]))
+            ps, pd, ns, nd = s2[0], d2[0], s2[1], d2[1]
             pos, ng = merge(ps, pd).squeeze(-1).sigmoid(), merge(ns, nd).squeeze(-1).sigmoid()
             loss = torch.nn.functional.binary_cross_entropy(torch.cat([pos, ng]), torch.cat([torch.ones_like(pos), torch.zeros_like(ng)]))
             opt.zero_grad()

@@ -141,3 +141,41 @@ def test_end_to_end_example_runs_and_beats_chance(monkeypatch):
     hist = mod.main()
     assert len(hist) == 2 and all(np.isfinite([h["train_loss"], h["val_ap"], h["val_auc"]]).all() for h in hist)
     assert hist[-1]["train_loss"] < 0.75 and hist[-1]["val_auc"] > 0.52           # trains stably; better than chance after two short epochs
+
+
+@pytest.mark.parametrize("name,equal_lengths", [("bip_p2_l64", True), ("hub_p4_l48", False)])
+def test_many_in_training_equals_separate_calls(name, equal_lengths):
+    """compute_src_dst_node_temporal_embeddings_many with autograd on: two calls of a step as ONE dense pass when both pad
+    to the same lengths (bip: positive and negative call, every window is full), call by call otherwise (hub: the second call
+    swaps the roles of the low-degree users and the hub items, so its padded lengths are swapped too) -- outputs and
+    parameter gradients equal those of two separate calls."""
+    c = gc.build_case(name)
+    model, _ = build_model(c)
+    model.eval()                                   # dropout off, autograd on
+    B = len(c["src"])
+    G = [torch.from_numpy(g).cuda() for g in (_loss_weights(c, 5) + _loss_weights(c, 6))]
+    src2, dst2 = (c["src"], c["neg_dst"]) if equal_lengths else (c["dst"], c["src"])
+    lens = model._seq_lens_groups(*(torch.from_numpy(np.stack(x)).cuda() for x in ([c["src"], src2], [c["dst"], dst2], [c["times"], c["times"]])),
+                                  torch.device("cuda:0"))
+    assert (lens[0] == lens[1]) == equal_lengths, lens
+
+    def loss_of(ps, pd, ns, nd):
+        return (ps * G[0]).sum() + (pd * G[1]).sum() + (ns * G[2]).sum() + (nd * G[3]).sum()
+
+    for p in model.parameters():
+        p.grad = None
+    ps, pd = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
+    ns, nd = model.compute_src_dst_node_temporal_embeddings(src2, dst2, c["times"])
+    loss_of(ps, pd, ns, nd).backward()
+    want = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    for p in model.parameters():
+        p.grad = None
+    s, d = model.compute_src_dst_node_temporal_embeddings_many(np.stack([c["src"], src2]), np.stack([c["dst"], dst2]), np.stack([c["times"], c["times"]]))
+    assert s.shape == (2, B, 172) and s.requires_grad
+    for got, ref in ((s[0], ps), (d[0], pd), (s[1], ns), (d[1], nd)):
+        assert float((got - ref).detach().abs().max()) <= 1e-6 * max(1.0, float(ref.detach().abs().max()))
+    loss_of(s[0], d[0], s[1], d[1]).backward()
+    for k, p in model.named_parameters():
+        ref = want[k]
+        tol = TOL * max(1.0, float(ref.abs().max()))
+        assert float((p.grad - ref).abs().max()) <= tol, k

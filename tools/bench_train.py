@@ -40,8 +40,12 @@ def batch(i):
 
 def step(i):
     src, dst, neg, t = batch(i)
-    ps, pd = model.compute_src_dst_node_temporal_embeddings(src, dst, t)
-    ns, nd = model.compute_src_dst_node_temporal_embeddings(src, neg, t)
+    if os.environ.get("SEPARATE_CALLS", "0") == "1":      # the reference's call pattern (train_link_prediction.py:229-239), two dense passes
+        ps, pd = model.compute_src_dst_node_temporal_embeddings(src, dst, t)
+        ns, nd = model.compute_src_dst_node_temporal_embeddings(src, neg, t)
+    else:                                                   # both calls as one set: one dense pass when they pad to the same lengths
+        s2, d2 = model.compute_src_dst_node_temporal_embeddings_many(np.stack([src, src]), np.stack([dst, neg]), np.stack([t, t]))
+        ps, pd, ns, nd = s2[0], d2[0], s2[1], d2[1]
     pos, ng = merge(ps, pd).squeeze(-1).sigmoid(), merge(ns, nd).squeeze(-1).sigmoid()
     loss = torch.nn.functional.binary_cross_entropy(torch.cat([pos, ng]), torch.cat([torch.ones_like(pos), torch.zeros_like(ng)]))
     opt.zero_grad()
