@@ -34,6 +34,7 @@ struct MM {
     int relu;               // epilogue max(v, 0) (not combined with split-K)
     int ksplit, kchunk;     // split-K: blockIdx.z = batch * ksplit + part; part sums k in [part*kchunk, +kchunk) and adds atomically
     float* colsum;          // transA products only: colsum[m] += sum_k op(A)[m][k] (the bias gradient next to a weight gradient), or null
+    const int32_t* m_dev;   // optional device-side row count (<= M): workgroups whose rows all lie beyond it exit at once
 };
 
 __global__ __launch_bounds__(256) void k_mm(const MM p) {
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256) void k_mm(const MM p) {
     const float* Bm = p.B + zb * p.sBb + zh * p.sBh;
     float* C = p.C + zb * p.sCb + zh * p.sCh;
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    if (p.m_dev && m0 >= *p.m_dev) return;
     const int kbeg = ks * p.kchunk, kend = kbeg + p.kchunk < p.K ? kbeg + p.kchunk : p.K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
     const float* Bm = p.B + zb * p.sBb + zh * p.sBh;
     float* C = p.C + zb * p.sCb + zh * p.sCh;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (p.m_dev && m0 >= *p.m_dev) return;        // uniform over the workgroup, before any barrier
     const int kbeg = ks * p.kchunk, kend = kbeg + p.kchunk < p.K ? kbeg + p.kchunk : p.K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave >> 1, wx = wave & 1;
@@ -239,9 +242,9 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
 static int colsum(hipStream_t s, const float* A, int lda, int64_t M, int N, float* out, bool accumulate = false);
 
 int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb, bool tB, float* C, int ldc, int M, int N, int K, const float* bias, float alpha,
-       float beta, int batch, int H, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, bool relu, bool c_is_zero, float* colsum_out) {
+       float beta, int batch, int H, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, bool relu, bool c_is_zero, float* colsum_out, const int32_t* m_dev) {
     if (M <= 0 || N <= 0 || batch <= 0) return DYGNN_OK;
-    MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh, relu ? 1 : 0, 1, K, nullptr};
+    MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh, relu ? 1 : 0, 1, K, nullptr, m_dev};
     if (colsum_out) {                 // rides along inside the 64-row-tile kernel; anything else gets the stand-alone reduction
         if (tA && batch == 1 && M >= 48 && N >= 48) p.colsum = colsum_out;
         else if (int rc = colsum(s, A, lda, K, M, colsum_out)) return rc;

@@ -8,6 +8,7 @@
 //   sample_recent -> query projection -> W_k^T q per head -> attention over the k neighbours' INPUT rows (gathered on the
 //   fly; K and V are never materialised, see k_tgat_attn_lin) -> W_v z per head -> residual_fc + residual + LayerNorm ->
 //   MergeLayer.  All products go through the library's general fp32-MFMA GEMM (gemm.h).
+#include <cstdlib>
 #include "common.h"
 #include "gemm.h"
 
@@ -41,10 +42,10 @@ __global__ __launch_bounds__(256) void k_tgat_expand(const int64_t* __restrict__
                                                        const int32_t* __restrict__ ceid, const double* __restrict__ cts, int64_t num_nodes,
                                                        const int32_t* __restrict__ ids, const double* __restrict__ times, int64_t n, int k,
                                                        int32_t* __restrict__ lower_ids, double* __restrict__ lower_times,
-                                                       int32_t* __restrict__ nbr_eid, float* __restrict__ nbr_dt) {
+                                                       int32_t* __restrict__ nbr_eid, float* __restrict__ nbr_dt, const int32_t* __restrict__ n_live) {
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (q >= n) return;
+    if (q >= n || (n_live && q >= *n_live)) return;      // n = layout size of the level, *n_live = entries in use (de-duplicated level)
     int64_t node = ids[q];
     if (node < 0 || node >= num_nodes) node = 0;
     const double t = times[q];
@@ -74,9 +75,11 @@ __global__ __launch_bounds__(256) void k_tgat_inputs(const float* __restrict__ h
                                                        const float* __restrict__ edge_feat, const int32_t* __restrict__ lower_ids,
                                                        const int32_t* __restrict__ nbr_eid, const float* __restrict__ nbr_dt,
                                                        const float* __restrict__ tw, const float* __restrict__ tb, int64_t n, int k, int Fn, int Fe,
-                                                       int Ft, float* __restrict__ kv_in, float* __restrict__ q_in) {
+                                                       int Ft, float* __restrict__ kv_in, float* __restrict__ q_in, const int32_t* __restrict__ n_live,
+                                                       const int32_t* __restrict__ lower_map) {
     // row r in [0, n*k): neighbour (i = r / k, j = r % k) = lower-level entry n + r ; rows n*k .. n*k+n-1: the query rows
     const int64_t r = kv_in ? (int64_t)blockIdx.x : n * k + blockIdx.x;      // kv_in == NULL: query rows only
+    if (n_live && !kv_in && (int64_t)blockIdx.x >= *n_live) return;
     const int Kkv = Fn + Fe + Ft, Kq = Fn + Ft;
     if (r < n * k) {
         const int64_t le = n + r;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void k_tgat_inputs(const float* __restrict__ h
         }
     } else {
         const int64_t i = r - n * k;
-        const float* hsrc = h_lower ? h_lower + i * Fn : node_feat + (size_t)lower_ids[i] * Fn;
+        const float* hsrc = h_lower ? h_lower + (lower_map ? (int64_t)lower_map[i] : i) * Fn : node_feat + (size_t)lower_ids[i] * Fn;
         float* o = q_in + i * Kq;
         for (int f = threadIdx.x; f < Kq; f += blockDim.x) o[f] = f < Fn ? hsrc[f] : cosf(fmaf(0.0f, tw[f - Fn], tb[f - Fn]));
     }
@@ -359,13 +362,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                           const float* __restrict__ edge_feat, const int32_t* __restrict__ lower_ids,
                                                           const int32_t* __restrict__ nbr_eid, const float* __restrict__ nbr_dt, const float* __restrict__ tw,
                                                           const float* __restrict__ tb, int64_t n, int k, int Fn, int Fe, int Ft, int H, float scale,
-                                                          float* __restrict__ z) {
+                                                          float* __restrict__ z, const int32_t* __restrict__ n_live, const int32_t* __restrict__ lower_map) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hf = wave & 1, slot = wave >> 1;
     int64_t i = (int64_t)blockIdx.x * 2 + slot;
-    const bool live = i < n;
-    if (!live) i = n - 1;                                   // keeps the barrier uniform; nothing is written
+    const int64_t nl = n_live ? (int64_t)*n_live : n;      // entries in use (a de-duplicated level keeps the layout size n)
+    if ((int64_t)blockIdx.x * 2 >= nl) return;              // whole workgroup beyond the live entries
+    const bool live = i < nl;
+    if (!live) i = nl - 1;                                  // keeps the barrier uniform; nothing is written
     const int Dkv = Fn + Fe + Ft, D4 = Dkv >> 2, T0 = (Fn + Fe) >> 2, NT4 = Ft >> 2;
     const int par = (hf - T0) & 1;                          // parity, inside the time block, of the time columns this half owns
     const int ntc = (NT4 - par + 1) >> 1;                   // how many of them
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
             const int64_t r = r0 + (j < k ? j : 0);
-            const int64_t nrow = h_lower ? n + r : (int64_t)lower_ids[n + r];
+            const int64_t nrow = h_lower ? (lower_map ? (int64_t)lower_map[n + r] : n + r) : (int64_t)lower_ids[n + r];
             const int64_t erow = nbr_eid[r];
             xs[j] = *reinterpret_cast<const f4*>(bp + (cls == 0 ? nrow : erow) * st);
         }
@@ -462,10 +467,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // row [Dq + Fn]; the raw node features fill the rest (models/TGAT.py:134, models/modules.py:64)
 __global__ __launch_bounds__(256) void k_tgat_post(const float* __restrict__ fc_out, const float* __restrict__ q_in, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const float* __restrict__ node_feat,
-                                                     const int32_t* __restrict__ lower_ids, int64_t n, int Dq, int Fn, float* __restrict__ merge_in) {
+                                                     const int32_t* __restrict__ lower_ids, int64_t n, int Dq, int Fn, float* __restrict__ merge_in,
+                                                     const int32_t* __restrict__ n_live) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n) return;
+    if (i >= n || (n_live && i >= *n_live)) return;
     float s = 0.f;
     for (int f = lane; f < Dq; f += kWave) s += fc_out[i * Dq + f] + q_in[i * Dq + f];
 #pragma unroll
@@ -480,6 +486,48 @@ __global__ __launch_bounds__(256) void k_tgat_post(const float* __restrict__ fc_
     for (int f = lane; f < Dq; f += kWave) o[f] = (fc_out[i * Dq + f] + q_in[i * Dq + f] - mean) * rstd * gamma[f] + beta[f];
     const float* raw = node_feat + (size_t)lower_ids[i] * Fn;
     for (int f = lane; f < Fn; f += kWave) o[Dq + f] = raw[f];
+}
+
+// ---- de-duplication of a level (recent sampling only) --------------------------------------------------------------------
+// Entries of a level are (node, time) queries.  With `recent` sampling an entry's embedding is a function of that pair alone, and
+// the level below the roots repeats itself: consecutive interactions of a node share 19 of their 20 most recent neighbours, and
+// both endpoints of an edge list it (at Reddit shape, 16 steps per call: 128,000 queries, 46,000 distinct).  Distinct entries
+// are found with an open-addressing table keyed by (node, time bits): the first thread to claim a slot is the representative,
+// every other entry with an equal key maps to it.  Which duplicate wins is a race, but all of them would compute the same row,
+// so results do not depend on it.  canon[i] = representative entry; the representatives are then numbered (cidx) and copied
+// into the compact level (cids, ctimes); map[i] = compact index of entry i.
+__device__ __forceinline__ uint32_t dedup_hash(int32_t id, double t) {
+    uint64_t z = (uint64_t)__double_as_longlong(t) ^ ((uint64_t)(uint32_t)id * 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)(z ^ (z >> 31));
+}
+__global__ void k_dedup_insert(const int32_t* __restrict__ ids, const double* __restrict__ times, int64_t n, int32_t* __restrict__ slots, uint32_t cap_mask,
+                               int32_t* __restrict__ canon) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t id = ids[i];
+    const double t = times[i];
+    uint32_t h = dedup_hash(id, t) & cap_mask;
+    for (;;) {
+        const int32_t prev = atomicCAS(&slots[h], -1, (int32_t)i);
+        if (prev == -1) { canon[i] = (int32_t)i; return; }
+        if (ids[prev] == id && __double_as_longlong(times[prev]) == __double_as_longlong(t)) { canon[i] = prev; return; }
+        h = (h + 1) & cap_mask;
+    }
+}
+__global__ void k_dedup_number(const int32_t* __restrict__ ids, const double* __restrict__ times, const int32_t* __restrict__ canon, int64_t n,
+                               int32_t* __restrict__ count, int32_t* __restrict__ cidx, int32_t* __restrict__ cids, double* __restrict__ ctimes) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || canon[i] != (int32_t)i) return;
+    const int32_t c = atomicAdd(count, 1);
+    cidx[i] = c;
+    cids[c] = ids[i];
+    ctimes[c] = times[i];
+}
+__global__ void k_dedup_map(const int32_t* __restrict__ canon, const int32_t* __restrict__ cidx, int64_t n, int32_t* __restrict__ map) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) map[i] = cidx[canon[i]];
 }
 
 __global__ void k_cast_ids(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const double* __restrict__ t, int64_t B,
@@ -503,6 +551,9 @@ struct TgatPlan {
     // byte offsets
     size_t ids[DYGNN_MAX_LAYERS + 1], times[DYGNN_MAX_LAYERS + 1], eid[DYGNN_MAX_LAYERS + 1], dt[DYGNN_MAX_LAYERS + 1], h[DYGNN_MAX_LAYERS + 1];
     size_t q_in, q, att, fc, merge_in, hid, qk, z, total;
+    // de-duplication of level L-1 (two-layer models, recent sampling): hash slots, representative / compact index / map per entry, compact level
+    size_t dd_slots, dd_canon, dd_cidx, dd_map, dd_count, dd_ids, dd_times;
+    uint32_t dd_cap;
 };
 
 static TgatPlan make_tgat_plan(const dygnn_tgat_config& c, int64_t B) {
@@ -529,6 +580,17 @@ static TgatPlan make_tgat_plan(const dygnn_tgat_config& c, int64_t B) {
     p.fc = take((size_t)nmax * p.Dq * sizeof(float));
     p.merge_in = take((size_t)nmax * (p.Dq + p.Fn) * sizeof(float));
     p.hid = take((size_t)nmax * p.Fn * sizeof(float));
+    if (p.L == 2) {
+        p.dd_cap = 1024;
+        while ((int64_t)p.dd_cap < 2 * p.n[1]) p.dd_cap <<= 1;
+        p.dd_slots = take((size_t)p.dd_cap * sizeof(int32_t));
+        p.dd_canon = take((size_t)p.n[1] * sizeof(int32_t));
+        p.dd_cidx = take((size_t)p.n[1] * sizeof(int32_t));
+        p.dd_map = take((size_t)p.n[1] * sizeof(int32_t));
+        p.dd_count = take(sizeof(int32_t));
+        p.dd_ids = take((size_t)p.n[1] * sizeof(int32_t));
+        p.dd_times = take((size_t)p.n[1] * sizeof(double));
+    }
     p.total = o;
     return p;
 }
@@ -550,9 +612,9 @@ static int check_tgat(const dygnn_tgat_config* c) {
 }
 
 template <bool RELU>
-static int gemm_nt(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, int ldc, hipStream_t s) {
+static int gemm_nt(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, int ldc, hipStream_t s, const int32_t* m_dev = nullptr) {
     if (M == 0) return DYGNN_OK;
-    if (M >= 48) return train::mm(s, A, K, false, W, K, true, C, ldc, (int)M, N, K, bias, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, RELU);      // the LDS-tiled general GEMM
+    if (M >= 48 || m_dev) return train::mm(s, A, K, false, W, K, true, C, ldc, (int)M, N, K, bias, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, RELU, false, nullptr, m_dev);      // the LDS-tiled general GEMM
     hipLaunchKernelGGL((k_gemm_nt<RELU>), dim3((unsigned)ceil_div(M, 256), (unsigned)ceil_div(N, 64)), dim3(256), 0, s, A, W, bias, C, M, N, K, ldc);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
@@ -593,6 +655,11 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
     auto I32 = [&](size_t off) { return reinterpret_cast<int32_t*>(ws + off); };
     auto F64 = [&](size_t off) { return reinterpret_cast<double*>(ws + off); };
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    // Distinct entries of level 1 are computed once (see k_dedup_insert): only when the library samples itself (`recent` is a function of
+    // (node, time); pre-sampled random levels draw independently per entry) and the pair attention kernel, which knows the row map, applies.
+    const char* dd_env = getenv("DYGNN_TGAT_DEDUP");                 // "0" switches it off (read per call: the A/B switch of tests/test_tgat.py)
+    const bool dedup_on = !(dd_env && dd_env[0] == '0');
+    const bool dedup = dedup_on && !levels && p.L == 2 && p.k <= 20 && p.H <= 2 && p.Dkv <= 512;
 
     if (levels) {
         // pre-sampled levels (random strategies): copy them where the sampling kernels would have written them
@@ -610,9 +677,24 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
     DYGNN_LAUNCH_CHECK();
     // top-down: sample neighbours of every level, building the level below
     for (int l = p.L; l >= 1; --l) {
+        const bool dd = dedup && l == 1;          // level 1 is expanded from its distinct entries only
         hipLaunchKernelGGL(k_tgat_expand, dim3((unsigned)ceil_div(p.n[l], 4)), dim3(256), 0, s, csr->indptr, csr->nbr, csr->eid, csr->ts, csr->num_nodes,
-                           I32(p.ids[l]), F64(p.times[l]), p.n[l], p.k, I32(p.ids[l - 1]), F64(p.times[l - 1]), I32(p.eid[l]), F32(p.dt[l]));
+                           dd ? I32(p.dd_ids) : I32(p.ids[l]), dd ? F64(p.dd_times) : F64(p.times[l]), p.n[l], p.k, I32(p.ids[l - 1]), F64(p.times[l - 1]),
+                           I32(p.eid[l]), F32(p.dt[l]), dd ? I32(p.dd_count) : (const int32_t*)nullptr);
         DYGNN_LAUNCH_CHECK();
+        if (dedup && l == 2) {                    // level 1 is complete: find its distinct (node, time) entries
+            const int64_t n1 = p.n[1];
+            DYGNN_HIP(hipMemsetAsync(I32(p.dd_slots), 0xFF, (size_t)p.dd_cap * sizeof(int32_t), s));
+            DYGNN_HIP(hipMemsetAsync(I32(p.dd_count), 0, sizeof(int32_t), s));
+            hipLaunchKernelGGL(k_dedup_insert, dim3((unsigned)ceil_div(n1, 256)), dim3(256), 0, s, I32(p.ids[1]), F64(p.times[1]), n1, I32(p.dd_slots), p.dd_cap - 1,
+                               I32(p.dd_canon));
+            DYGNN_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_dedup_number, dim3((unsigned)ceil_div(n1, 256)), dim3(256), 0, s, I32(p.ids[1]), F64(p.times[1]), I32(p.dd_canon), n1, I32(p.dd_count),
+                               I32(p.dd_cidx), I32(p.dd_ids), F64(p.dd_times));
+            DYGNN_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_dedup_map, dim3((unsigned)ceil_div(n1, 256)), dim3(256), 0, s, I32(p.dd_canon), I32(p.dd_cidx), n1, I32(p.dd_map));
+            DYGNN_LAUNCH_CHECK();
+        }
     }
     }
     // bottom-up: layer l turns level-(l-1) embeddings (raw features for l = 1) into level-l embeddings
@@ -621,20 +703,22 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
         const dygnn_tgat_layer_weights& Lw = w->layers[l - 1];
         const int64_t n = p.n[l];
         const float* h_lower = l >= 2 ? F32(p.h[l - 1]) : nullptr;
+        const int32_t* nl = dedup && l == 1 ? I32(p.dd_count) : nullptr;       // layer 1 runs over the distinct level-1 entries (count on the device)
+        const int32_t* lmap = dedup && l == 2 ? I32(p.dd_map) : nullptr;       // layer 2 finds an entry's layer-1 row through the map
         hipLaunchKernelGGL(k_tgat_inputs, dim3((unsigned)n), dim3(256), 0, s, h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]),
-                           F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, (float*)nullptr, F32(p.q_in));     // query rows
+                           F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, (float*)nullptr, F32(p.q_in), nl, lmap);     // query rows
         DYGNN_LAUNCH_CHECK();
-        if (int rc = gemm_nt<false>(F32(p.q_in), Lw.query_w, nullptr, F32(p.q), n, p.Dq, p.Dq, p.Dq, s)) return rc;
+        if (int rc = gemm_nt<false>(F32(p.q_in), Lw.query_w, nullptr, F32(p.q), n, p.Dq, p.Dq, p.Dq, s, nl)) return rc;
         // qk[i][h] = W_k,h^T q_ih : per head [n][hd] x [hd][Dkv] (rows h*hd .. of key_w), one batched launch over the heads
         if (int rc = train::mm(s, F32(p.q), p.Dq, false, Lw.key_w, p.Dkv, false, F32(p.qk), p.H * p.Dkv, (int)n, p.Dkv, p.hd, nullptr, 1.f, 0.f, p.H, p.H, 0, p.hd,
-                               0, (int64_t)p.hd * p.Dkv, 0, p.Dkv)) return rc;
+                               0, (int64_t)p.hd * p.Dkv, 0, p.Dkv, false, false, nullptr, nl)) return rc;
         const dim3 grid((unsigned)ceil_div(n, 4));
         const size_t lds = (size_t)4 * p.H * p.k * sizeof(float);
         if (p.k <= 20 && p.H <= 2 && p.Dkv <= 512) {
             const int TW = 4 * ((p.Ft / 4 + 1) / 2);
             const size_t lds2 = ((size_t)8 * p.H * 20 + (size_t)4 * 20 * TW) * sizeof(float);
             hipLaunchKernelGGL((k_tgat_attn_pair<20>), dim3((unsigned)ceil_div(n, 2)), dim3(256), lds2, s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]),
-                               F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z));
+                               F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z), nl, lmap);
         } else if (p.k <= 20)
             hipLaunchKernelGGL((k_tgat_attn_lin<20>), grid, dim3(256), lds + (size_t)4 * 20 * p.Ft * sizeof(float), s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]), F32(p.dt[l]),
                                w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z));
@@ -644,13 +728,13 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
         DYGNN_LAUNCH_CHECK();
         // att[i][h*hd ..] = W_v,h z_ih : per head [n][Dkv] x [Dkv][hd]
         if (int rc = train::mm(s, F32(p.z), p.H * p.Dkv, false, Lw.value_w, p.Dkv, true, F32(p.att), p.Dq, (int)n, p.hd, p.Dkv, nullptr, 1.f, 0.f, p.H, p.H, 0, p.Dkv,
-                               0, (int64_t)p.hd * p.Dkv, 0, p.hd)) return rc;
-        if (int rc = gemm_nt<false>(F32(p.att), Lw.res_w, Lw.res_b, F32(p.fc), n, p.Dq, p.Dq, p.Dq, s)) return rc;
+                               0, (int64_t)p.hd * p.Dkv, 0, p.hd, false, false, nullptr, nl)) return rc;
+        if (int rc = gemm_nt<false>(F32(p.att), Lw.res_w, Lw.res_b, F32(p.fc), n, p.Dq, p.Dq, p.Dq, s, nl)) return rc;
         hipLaunchKernelGGL(k_tgat_post, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, s, F32(p.fc), F32(p.q_in), Lw.ln_w, Lw.ln_b, node_feat, I32(p.ids[l - 1]),
-                           n, p.Dq, p.Fn, F32(p.merge_in));
+                           n, p.Dq, p.Fn, F32(p.merge_in), nl);
         DYGNN_LAUNCH_CHECK();
-        if (int rc = gemm_nt<true>(F32(p.merge_in), Lw.fc1_w, Lw.fc1_b, F32(p.hid), n, p.Fn, p.Dq + p.Fn, p.Fn, s)) return rc;
-        if (int rc = gemm_nt<false>(F32(p.hid), Lw.fc2_w, Lw.fc2_b, F32(p.h[l]), n, p.Fn, p.Fn, p.Fn, s)) return rc;
+        if (int rc = gemm_nt<true>(F32(p.merge_in), Lw.fc1_w, Lw.fc1_b, F32(p.hid), n, p.Fn, p.Dq + p.Fn, p.Fn, s, nl)) return rc;
+        if (int rc = gemm_nt<false>(F32(p.hid), Lw.fc2_w, Lw.fc2_b, F32(p.h[l]), n, p.Fn, p.Fn, p.Fn, s, nl)) return rc;
     }
     hipLaunchKernelGGL(k_split_out, dim3((unsigned)ceil_div(2 * batch * p.Fn, 256)), dim3(256), 0, s, F32(p.h[p.L]), batch, p.Fn, out_src, out_dst);
     DYGNN_LAUNCH_CHECK();

@@ -89,10 +89,10 @@ def evaluate_model_link_prediction(model_name: str, model: nn.Module, neighbor_s
             prob = merge.link_probabilities(a.reshape(2 * n * B, -1), b.reshape(2 * n * B, -1)).reshape(2, n, B)
         elif model_name == "TGAT" and neighbor_sampler.sample_neighbor_strategy == "recent":
             # rows do not depend on the batch they are in (fixed k, stateless sampling): the n batches are one call on n*B edges
-            cat = lambda gs, c: np.concatenate([g[c] for g in gs])
-            pe = backbone.compute_src_dst_node_temporal_embeddings(cat(groups_pos, 0), cat(groups_pos, 1), cat(groups_pos, 2), num_neighbors=num_neighbors)
-            ne = backbone.compute_src_dst_node_temporal_embeddings(cat(groups_neg, 0), cat(groups_neg, 1), cat(groups_neg, 2), num_neighbors=num_neighbors)
-            prob = torch.stack([merge.link_probabilities(*pe).reshape(n, B), merge.link_probabilities(*ne).reshape(n, B)])
+            # positives and negatives in ONE call: level de-duplication (tgat.hip) then computes the shared source side once
+            cat = lambda c: np.concatenate([g[c] for g in groups_pos] + [g[c] for g in groups_neg])
+            emb = backbone.compute_src_dst_node_temporal_embeddings(cat(0), cat(1), cat(2), num_neighbors=num_neighbors)
+            prob = merge.link_probabilities(*emb).reshape(2, n, B)
         elif model_name == "TGAT":      # random strategies consume the sampler's RandomState call by call: keep the reference's call order
             probs = []
             for gp, gn in zip(groups_pos, groups_neg):

@@ -120,3 +120,26 @@ def test_hip_rows_do_not_depend_on_the_batch_they_are_in():
             sl = slice(200 * j, 200 * (j + 1))
             ss, sd = m.compute_src_dst_node_temporal_embeddings(src[sl], dst[sl], t[sl], num_neighbors=20)
             assert torch.equal(fs[sl], ss) and torch.equal(fd[sl], sd), j
+
+
+@pytest.mark.gpu
+def test_hip_level_deduplication_changes_nothing(monkeypatch):
+    """two-layer `recent` TGAT computes every distinct (node, time) entry of level 1 once (k_dedup_*): the result is bit-identical to
+    computing all of them (DYGNN_TGAT_DEDUP=0), on a batch where most level-1 entries are duplicates"""
+    from dyglib_amd import TGAT, get_neighbor_sampler
+    data, nf, ef = syn.make_bipartite_graph(300, 40, 20000, seed=33)
+    nf[1:] = np.random.RandomState(6).standard_normal(nf[1:].shape).astype(np.float32) * 0.5
+    sampler = get_neighbor_sampler(data, "recent", seed=1, device="cuda:0")
+    m = TGAT(nf, ef, sampler, 100, num_layers=2, num_heads=2, dropout=0.1, device="cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_tgat_params(10).items()})
+    m = m.to("cuda:0").eval()
+    idx = np.concatenate([np.arange(5), np.arange(data.num_interactions - 1200, data.num_interactions)])      # incl. nodes without history
+    src, dst, t = data.src_node_ids[idx], data.dst_node_ids[idx], data.node_interact_times[idx]
+    with torch.no_grad():
+        monkeypatch.setenv("DYGNN_TGAT_DEDUP", "0")
+        a_s, a_d = m.compute_src_dst_node_temporal_embeddings(src, dst, t, num_neighbors=20)
+        monkeypatch.setenv("DYGNN_TGAT_DEDUP", "1")
+        b_s, b_d = m.compute_src_dst_node_temporal_embeddings(src, dst, t, num_neighbors=20)
+        c_s, c_d = m.compute_src_dst_node_temporal_embeddings(src, dst, t, num_neighbors=20)
+    assert torch.equal(a_s, b_s) and torch.equal(a_d, b_d)
+    assert torch.equal(b_s, c_s) and torch.equal(b_d, c_d)            # and it is reproducible although the representatives are chosen by a race
