@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported first: see module docstring)
 from . import _build
 
 DYGNN_MAX_LAYERS = 8
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -126,6 +126,7 @@ SIGNATURES = {
                                            C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dygnn_merge_layer_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dygnn_tgat_level_entries": (C.c_int, [C.POINTER(TgatConfig), C.c_int64, C.c_void_p, c_i64p, c_i64p, C.c_void_p]),
     "dygnn_link_metrics_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "dygnn_link_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p]),

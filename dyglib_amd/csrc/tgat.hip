@@ -840,6 +840,23 @@ extern "C" int dygnn_tgat_forward_levels(const dygnn_tgat_config* cfg, const dyg
     return tgat_forward_impl(cfg, w, nullptr, node_feat, edge_feat, nullptr, nullptr, nullptr, batch, out_src, out_dst, workspace, workspace_bytes, stream, levels);
 }
 
+extern "C" int dygnn_tgat_level_entries(const dygnn_tgat_config* cfg, int64_t batch, const void* workspace, int64_t* total, int64_t* computed,
+                                        dygnn_stream_t stream) {
+    if (int rc = check_tgat(cfg)) return rc;
+    DYGNN_REQUIRE(batch > 0 && workspace && total && computed, "tgat_level_entries: bad arguments");
+    const TgatPlan p = make_tgat_plan(*cfg, batch);
+    *total = 0;
+    for (int l = 1; l <= p.L; ++l) *total += p.n[l];
+    *computed = *total;
+    if (p.L == 2) {
+        int32_t u = 0;
+        DYGNN_HIP(hipMemcpyAsync(&u, static_cast<const char*>(workspace) + p.dd_count, sizeof(u), hipMemcpyDeviceToHost, as_stream(stream)));
+        DYGNN_HIP(hipStreamSynchronize(as_stream(stream)));
+        if (u > 0 && u <= p.n[1]) *computed = p.n[2] + u;
+    }
+    return DYGNN_OK;
+}
+
 extern "C" int dygnn_tgat_forward(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_csr* csr, const float* node_feat,
                                   const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
                                   float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {

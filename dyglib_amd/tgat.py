@@ -111,11 +111,20 @@ class TGAT(nn.Module):
                                                             ws.data_ptr(), ws.numel(), _capi.current_stream_ptr()))
             torch.cuda.current_stream(dev).synchronize()          # `keep` (the level tensors) may be freed afterwards
             return out_src, out_dst
+        self._last_call = (cfg, B, ws)
         _capi.check(self._lib.dygnn_tgat_forward(C.byref(cfg), C.byref(w), self.neighbor_sampler.csr.on_device(dev),
                                                  self.node_raw_features.data_ptr(), self.edge_raw_features.data_ptr(),
                                                  src.data_ptr(), dst.data_ptr(), tms.data_ptr(), B, out_src.data_ptr(), out_dst.data_ptr(),
                                                  ws.data_ptr(), ws.numel(), _capi.current_stream_ptr()))
         return out_src, out_dst
+
+    def last_level_entries(self) -> Tuple[int, int]:
+        """(entries over the computed levels, entries actually computed) of the last `recent` call: two-layer models compute every
+        distinct (node, time) entry of level 1 once (dygnn_tgat_level_entries; synchronises the stream)."""
+        cfg, B, ws = self._last_call
+        total, computed = C.c_int64(0), C.c_int64(0)
+        _capi.check(self._lib.dygnn_tgat_level_entries(C.byref(cfg), B, ws.data_ptr(), C.byref(total), C.byref(computed), _capi.current_stream_ptr()))
+        return int(total.value), int(computed.value)
 
     # ---- random sampling strategies: the draws are replayed on the host in the reference's recursion order ----------------
     def _sample_levels_host(self, src: np.ndarray, dst: np.ndarray, t: np.ndarray, k: int, dev):

@@ -229,6 +229,12 @@ int dygnn_tgat_forward_levels(const dygnn_tgat_config* cfg_host, const dygnn_tga
                               const float* node_feat, const float* edge_feat, int64_t batch,
                               float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
 
+/* Diagnostic (synchronises `stream`): how many (node, time) entries the LAST dygnn_tgat_forward call on `workspace` (same cfg / batch)
+ * had over its computed levels (*total = sum of the level sizes n_1 .. n_L, what the reference computes, models/TGAT.py:92-110) and how
+ * many the library computed (*computed): with `recent` sampling a two-layer model computes every distinct entry of level 1 once. */
+int dygnn_tgat_level_entries(const dygnn_tgat_config* cfg_host, int64_t batch, const void* workspace, int64_t* total_host, int64_t* computed_host,
+                             dygnn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * TGN: MemoryModel.compute_src_dst_node_temporal_embeddings with model_name == 'TGN'
  * (models/MemoryModel.py:87-168): GRU memory update from the last pending raw message of every node

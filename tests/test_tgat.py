@@ -143,3 +143,11 @@ def test_hip_level_deduplication_changes_nothing(monkeypatch):
         c_s, c_d = m.compute_src_dst_node_temporal_embeddings(src, dst, t, num_neighbors=20)
     assert torch.equal(a_s, b_s) and torch.equal(a_d, b_d)
     assert torch.equal(b_s, c_s) and torch.equal(b_d, c_d)            # and it is reproducible although the representatives are chosen by a race
+    # the number of computed entries = roots + distinct (node, time) pairs of level 1 (roots at their float64 times, neighbours at float32 times)
+    total, computed = m.last_level_entries()
+    roots, rt = np.concatenate([src, dst]), np.concatenate([t, t])
+    nb, _, nt = sampler.get_historical_neighbors(roots, rt, 20)
+    ids1 = np.concatenate([roots, nb.reshape(-1)]).astype(np.int64)
+    t1 = np.concatenate([rt, nt.reshape(-1).astype(np.float64)])
+    distinct = len(set(zip(ids1.tolist(), t1.view(np.int64).tolist())))
+    assert total == 2 * len(src) * 22 and computed == 2 * len(src) + distinct and computed < total // 2
