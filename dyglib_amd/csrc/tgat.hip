@@ -868,11 +868,14 @@ extern "C" size_t dygnn_tgn_workspace_bytes(const dygnn_tgat_config* cfg, int64_
     return make_tgn_plan(*cfg, num_nodes, batch).total;
 }
 
-extern "C" int dygnn_tgn_forward(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_gru_weights* gru, const dygnn_csr* csr,
-                                 const float* node_feat, const float* edge_feat, const dygnn_tgn_state* st, const int64_t* src, const int64_t* dst,
-                                 const double* times, const int64_t* edge_ids, int64_t batch, int32_t edges_are_positive, float* out_src,
-                                 float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
+// The first n_pos pairs of the batch are positive edges (they update the state), the rest only read it.
+static int tgn_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_gru_weights* gru, const dygnn_csr* csr,
+                            const float* node_feat, const float* edge_feat, const dygnn_tgn_state* st, const int64_t* src, const int64_t* dst,
+                            const double* times, const int64_t* edge_ids, int64_t batch, int64_t n_pos, float* out_src,
+                            float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
+    const bool edges_are_positive = n_pos > 0;
     if (int rc = check_tgat(cfg)) return rc;
+    DYGNN_REQUIRE(n_pos >= 0 && n_pos <= batch, "tgn: n_positive must be in [0, batch]");
     DYGNN_REQUIRE(gru && gru->weight_ih && gru->weight_hh && gru->bias_ih && gru->bias_hh, "tgn: null GRU weights");
     DYGNN_REQUIRE(st && st->memory && st->last_update && st->msg && st->msg_time && st->has_msg && st->num_nodes >= 1, "tgn: bad state");
     DYGNN_REQUIRE(batch >= 0 && node_feat && edge_feat && workspace, "tgn: bad arguments");
@@ -898,9 +901,9 @@ extern "C" int dygnn_tgn_forward(const dygnn_tgat_config* cfg, const dygnn_tgat_
     if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, ws + p.tgat, p.total - p.tgat, stream)) return rc;
     if (!edges_are_positive) return DYGNN_OK;
     // 3. persist + clear for the batch nodes (MemoryModel.py:142-145)
-    hipLaunchKernelGGL(k_tgn_persist, dim3((unsigned)(2 * batch)), dim3(64), 0, s, src, dst, batch, Mnew, st->msg_time, Fn, st->memory, st->last_update, st->has_msg);
+    hipLaunchKernelGGL(k_tgn_persist, dim3((unsigned)(2 * n_pos)), dim3(64), 0, s, src, dst, n_pos, Mnew, st->msg_time, Fn, st->memory, st->last_update, st->has_msg);
     DYGNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_tgn_clear, dim3((unsigned)ceil_div(2 * batch, 256)), dim3(256), 0, s, src, dst, batch, st->has_msg);
+    hipLaunchKernelGGL(k_tgn_clear, dim3((unsigned)ceil_div(2 * n_pos, 256)), dim3(256), 0, s, src, dst, n_pos, st->has_msg);
     DYGNN_LAUNCH_CHECK();
     // 4. new raw messages: source role first, then destination role (store order, MemoryModel.py:147-161)
     for (int role = 0; role < 2; ++role) {
@@ -908,11 +911,27 @@ extern "C" int dygnn_tgn_forward(const dygnn_tgat_config* cfg, const dygnn_tgat_
         const int64_t* other = role ? src : dst;
         hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, win, N, -1);
         DYGNN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_tgn_winner, dim3((unsigned)ceil_div(batch, 256)), dim3(256), 0, s, who, batch, win);
+        hipLaunchKernelGGL(k_tgn_winner, dim3((unsigned)ceil_div(n_pos, 256)), dim3(256), 0, s, who, n_pos, win);
         DYGNN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_tgn_message, dim3((unsigned)batch), dim3(256), 0, s, who, other, times, edge_ids, batch, st->memory, st->last_update, edge_feat,
+        hipLaunchKernelGGL(k_tgn_message, dim3((unsigned)n_pos), dim3(256), 0, s, who, other, times, edge_ids, n_pos, st->memory, st->last_update, edge_feat,
                            w->time_w, w->time_b, Fn, Fe, Ft, win, st->msg, st->msg_time, st->has_msg);
         DYGNN_LAUNCH_CHECK();
     }
     return DYGNN_OK;
+}
+
+extern "C" int dygnn_tgn_forward(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_gru_weights* gru, const dygnn_csr* csr,
+                                 const float* node_feat, const float* edge_feat, const dygnn_tgn_state* st, const int64_t* src, const int64_t* dst,
+                                 const double* times, const int64_t* edge_ids, int64_t batch, int32_t edges_are_positive, float* out_src,
+                                 float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
+    return tgn_forward_impl(cfg, w, gru, csr, node_feat, edge_feat, st, src, dst, times, edge_ids, batch, edges_are_positive ? batch : 0, out_src, out_dst,
+                            workspace, workspace_bytes, stream);
+}
+
+extern "C" int dygnn_tgn_forward_step(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_gru_weights* gru, const dygnn_csr* csr,
+                                      const float* node_feat, const float* edge_feat, const dygnn_tgn_state* st, const int64_t* src, const int64_t* dst,
+                                      const double* times, const int64_t* edge_ids, int64_t batch, int64_t n_positive, float* out_src,
+                                      float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
+    return tgn_forward_impl(cfg, w, gru, csr, node_feat, edge_feat, st, src, dst, times, edge_ids, batch, n_positive, out_src, out_dst, workspace,
+                            workspace_bytes, stream);
 }

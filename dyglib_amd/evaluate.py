@@ -100,14 +100,11 @@ def evaluate_model_link_prediction(model_name: str, model: nn.Module, neighbor_s
                 ne = backbone.compute_src_dst_node_temporal_embeddings(gn[0], gn[1], gn[2], num_neighbors=num_neighbors)
                 probs.append(torch.stack([merge.link_probabilities(*pe), merge.link_probabilities(*ne)]))
             prob = torch.stack(probs, dim=1)
-        else:       # TGN: strictly sequential; negatives first, they must not see the memories this batch's positives write (:85-107)
+        else:       # TGN: batches strictly in sequence; the negative and the positive call of a batch (:85-107) are one library call
             probs = []
             for gp, gn in zip(groups_pos, groups_neg):
-                ne = backbone.compute_src_dst_node_temporal_embeddings(gn[0], gn[1], gn[2], edge_ids=None, edges_are_positive=False,
-                                                                       num_neighbors=num_neighbors)
-                pe = backbone.compute_src_dst_node_temporal_embeddings(gp[0], gp[1], gp[2], edge_ids=gp[3], edges_are_positive=True,
-                                                                       num_neighbors=num_neighbors)
-                probs.append(torch.stack([merge.link_probabilities(*pe), merge.link_probabilities(*ne)]))
+                ps, pd, ns, nd = backbone.compute_step_embeddings(gp[0], gp[1], gn[0], gn[1], gp[2], gp[3], num_neighbors=num_neighbors)
+                probs.append(torch.stack([merge.link_probabilities(ps, pd), merge.link_probabilities(ns, nd)]))
             prob = torch.stack(probs, dim=1)
         predicts = torch.cat([prob[0], prob[1]], dim=1)                                     # :142
         labels = torch.cat([torch.ones_like(prob[0]), torch.zeros_like(prob[1])], dim=1)    # :143

@@ -120,8 +120,22 @@ class MemoryModel(nn.Module):
             assert neighbor_sampler.seed is not None
             neighbor_sampler.reset_random_state()
 
+    def compute_step_embeddings(self, src_node_ids, dst_node_ids, neg_src_node_ids, neg_dst_node_ids, node_interact_times, edge_ids,
+                                num_neighbors: int = 20):
+        """The negative call and the positive call of one batch (evaluate_models_utils.py:85-107) as ONE library call: both read the
+        same state and only the positive call writes it, at its end, so [positives ; negatives] is one batch whose first half updates the
+        memory bank (dygnn_tgn_forward_step).  Returns (src_emb, dst_emb, neg_src_emb, neg_dst_emb), bit-identical to
+        compute_src_dst_node_temporal_embeddings(neg..., edges_are_positive=False) followed by (...pos..., edges_are_positive=True)."""
+        cat = lambda a, b: (torch.cat([a, b]) if isinstance(a, torch.Tensor) else np.concatenate([np.asarray(a), np.asarray(b)]))
+        n_pos = len(src_node_ids)
+        s, d = self.compute_src_dst_node_temporal_embeddings(cat(src_node_ids, neg_src_node_ids), cat(dst_node_ids, neg_dst_node_ids),
+                                                             cat(node_interact_times, node_interact_times), edge_ids, edges_are_positive=True,
+                                                             num_neighbors=num_neighbors, _n_positive=n_pos)
+        return s[:n_pos], d[:n_pos], s[n_pos:], d[n_pos:]
+
     def compute_src_dst_node_temporal_embeddings(self, src_node_ids, dst_node_ids, node_interact_times, edge_ids,
-                                                 edges_are_positive: bool = True, num_neighbors: int = 20) -> Tuple[torch.Tensor, torch.Tensor]:
+                                                 edges_are_positive: bool = True, num_neighbors: int = 20, _n_positive: int = None
+                                                 ) -> Tuple[torch.Tensor, torch.Tensor]:
         """MemoryModel.py:87-168 (TGN).  Positive calls mutate the memory bank: issue batches in chronological order."""
         if self.training and torch.is_grad_enabled():
             raise NotImplementedError("training-mode forward / backward through the HIP path is not built yet (SURVEY.md §8f-1)")
@@ -169,9 +183,12 @@ class MemoryModel(nn.Module):
             if len(self._workspace) > 8:
                 self._workspace.clear()
             ws = self._workspace[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _capi.check(self._lib.dygnn_tgn_forward(C.byref(cfg), C.byref(w), C.byref(gru), sampler.csr.on_device(dev),
-                                                self.node_raw_features.data_ptr(), self.edge_raw_features.data_ptr(), C.byref(st),
-                                                src.data_ptr(), dst.data_ptr(), tms.data_ptr(), eids.data_ptr() if eids is not None else None,
-                                                B, 1 if edges_are_positive else 0, out_src.data_ptr(), out_dst.data_ptr(),
-                                                ws.data_ptr(), ws.numel(), _capi.current_stream_ptr()))
+        n_pos = (B if edges_are_positive else 0) if _n_positive is None else int(_n_positive)
+        if eids is not None and eids.numel() < n_pos:
+            raise AssertionError("edge_ids must cover the positive edges")
+        _capi.check(self._lib.dygnn_tgn_forward_step(C.byref(cfg), C.byref(w), C.byref(gru), sampler.csr.on_device(dev),
+                                                     self.node_raw_features.data_ptr(), self.edge_raw_features.data_ptr(), C.byref(st),
+                                                     src.data_ptr(), dst.data_ptr(), tms.data_ptr(), eids.data_ptr() if eids is not None else None,
+                                                     B, n_pos, out_src.data_ptr(), out_dst.data_ptr(),
+                                                     ws.data_ptr(), ws.numel(), _capi.current_stream_ptr()))
         return out_src, out_dst

@@ -265,6 +265,18 @@ int dygnn_tgn_forward(const dygnn_tgat_config* cfg_host, const dygnn_tgat_weight
                       int64_t batch, int32_t edges_are_positive, float* out_src, float* out_dst,
                       void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
 
+/* One evaluation / training step in ONE call (caller-side fusion): the reference issues the negative call and then the
+ * positive call of a batch (evaluate_models_utils.py:85-107); both read the same state -- only the positive call writes it, at its end --
+ * so the batch may hold both: the first n_positive pairs are the positive edges (they persist memories and leave new raw messages,
+ * edge_ids [n_positive]), the remaining batch - n_positive pairs only read.  Rows and the state left behind are bit-identical to
+ * dygnn_tgn_forward(negatives, edges_are_positive = 0) followed by dygnn_tgn_forward(positives, 1); the GRU update and every
+ * kernel launch happen once instead of twice.  n_positive = batch / 0 reproduces the two modes of dygnn_tgn_forward. */
+int dygnn_tgn_forward_step(const dygnn_tgat_config* cfg_host, const dygnn_tgat_weights* w_host, const dygnn_gru_weights* gru_host,
+                           const dygnn_csr* csr_host, const float* node_feat, const float* edge_feat, const dygnn_tgn_state* state_host,
+                           const int64_t* src, const int64_t* dst, const double* times, const int64_t* edge_ids /* [n_positive] */,
+                           int64_t batch, int64_t n_positive, float* out_src, float* out_dst,
+                           void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
+
 /* ---- training: train_link_prediction.py:229-257 on the HIP path ------------------------------------
  * dygnn_dygformer_train_forward = models/DyGFormer.py:68-194 in TRAIN mode: dropout (probability dropout_p) on the attention
  * probabilities, the attention output and the FFN (models/DyGFormer.py:429-431, :456-460), masks drawn from a counter-based

@@ -96,3 +96,35 @@ def test_hip_matches_golden(case):
         close(ps.cpu().numpy(), g["b2_pos_src"], name + " replay")
         with pytest.raises(AssertionError):
             m.compute_src_dst_node_temporal_embeddings(b["src"], b["dst"], b["t"], edge_ids=None, edges_are_positive=True, num_neighbors=k)
+
+
+@pytest.mark.gpu
+def test_fused_step_equals_negative_then_positive_call():
+    """compute_step_embeddings (dygnn_tgn_forward_step: [positives ; negatives] in one call, the first half updates the state) is
+    bit-identical, in its rows and in the memory bank it leaves behind, to the reference's negative call followed by the positive call"""
+    import torch
+    from dyglib_amd import MemoryModel, get_neighbor_sampler
+    c = gc.build_tgn_case("tgn_bip_l1_k10")
+    cfg, d, dev = c["tgn_cfg"], c["data"], "cuda:0"
+
+    def build():
+        sampler = get_neighbor_sampler(d, "recent", seed=1, device=dev)
+        m = MemoryModel(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"], model_name="TGN", num_layers=cfg["num_layers"],
+                        num_heads=cfg["num_heads"], dropout=0.1, device=dev)
+        sd = m.state_dict(); sd.update({k: torch.from_numpy(v) for k, v in c["tgn_params"].items()}); m.load_state_dict(sd)
+        m = m.to(dev).eval()
+        m.memory_bank.__init_memory_bank__()
+        return m
+
+    two, one = build(), build()
+    k = cfg["num_neighbors"]
+    with torch.no_grad():
+        for b in c["tgn_batches"]:
+            ns, nd = two.compute_src_dst_node_temporal_embeddings(b["src"], b["neg"], b["t"], edge_ids=None, edges_are_positive=False, num_neighbors=k)
+            ps, pd = two.compute_src_dst_node_temporal_embeddings(b["src"], b["dst"], b["t"], edge_ids=b["eid"], edges_are_positive=True, num_neighbors=k)
+            fs, fd, fns, fnd = one.compute_step_embeddings(b["src"], b["dst"], b["src"], b["neg"], b["t"], b["eid"], num_neighbors=k)
+            for x, y in ((ps, fs), (pd, fd), (ns, fns), (nd, fnd)):
+                assert torch.equal(x, y)
+    assert torch.equal(two.memory_bank.node_memories, one.memory_bank.node_memories)
+    assert torch.equal(two.memory_bank.node_last_updated_times, one.memory_bank.node_last_updated_times)
+    assert torch.equal(two.memory_bank.msg, one.memory_bank.msg) and torch.equal(two.memory_bank.has_msg, one.memory_bank.has_msg)

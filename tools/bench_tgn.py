@@ -11,6 +11,7 @@ from dyglib_amd import MemoryModel, MergeLayer, get_neighbor_sampler, synthetic 
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=100); ap.add_argument("--warmup", type=int, default=10); ap.add_argument("--cpu-steps", type=int, default=10)
+ap.add_argument("--two-calls", action="store_true", help="negative call then positive call per step, as the reference issues them")
 ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per step instead of issuing its ~50 launches (measured: no gain, "
                 "257 k vs 262 k edges/s -- the step is bound by the GPU-side latency of ~50 dependent small kernels, not by the host)")
 args = ap.parse_args()
@@ -31,9 +32,13 @@ def step(i):
     return step_on(*batches[i])
 def step_on(s, d, ng, t, e):
     with torch.no_grad():
-        a, b_ = model.compute_src_dst_node_temporal_embeddings(s, ng, t, edge_ids=None, edges_are_positive=False, num_neighbors=K)
-        c, f = model.compute_src_dst_node_temporal_embeddings(s, d, t, edge_ids=e, edges_are_positive=True, num_neighbors=K)
-        return merge.link_probabilities(c, f), merge.link_probabilities(a, b_)
+        if args.two_calls:       # the reference's call pattern: negative call, then positive call (evaluate_models_utils.py:85-107)
+            a, b_ = model.compute_src_dst_node_temporal_embeddings(s, ng, t, edge_ids=None, edges_are_positive=False, num_neighbors=K)
+            c, f = model.compute_src_dst_node_temporal_embeddings(s, d, t, edge_ids=e, edges_are_positive=True, num_neighbors=K)
+            return merge.link_probabilities(c, f), merge.link_probabilities(a, b_)
+        c, f, a, b_ = model.compute_step_embeddings(s, d, s, ng, t, e, num_neighbors=K)      # both calls as one (same state, written once at the end)
+        p = merge.link_probabilities(torch.cat([c, a]), torch.cat([f, b_]))
+        return p[:B], p[B:]
 model.memory_bank.__init_memory_bank__()
 for i in range(args.warmup): step(i)
 run = step
