@@ -630,10 +630,15 @@ extern "C" size_t dygnn_tgat_workspace_bytes(const dygnn_tgat_config* cfg, int64
 }
 
 namespace dygnn {
+static bool tgat_dedup_active(const TgatPlan& p, bool presampled) {
+    const char* dd_env = getenv("DYGNN_TGAT_DEDUP");                 // "0" switches it off (read per call: the A/B switch of tests/test_tgat.py)
+    const bool dedup_on = !(dd_env && dd_env[0] == '0');
+    return dedup_on && !presampled && p.L == 2 && p.k <= 20 && p.H <= 2 && p.Dkv <= 512;
+}
 static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_csr* csr, const float* node_feat,
                              const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
                              float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream,
-                             const dygnn_tgat_levels* levels = nullptr) {
+                             const dygnn_tgat_levels* levels = nullptr, bool levels_in_workspace = false, bool expand_only = false) {
     if (int rc = check_tgat(cfg)) return rc;
     DYGNN_REQUIRE(w && w->time_w && w->time_b, "tgat: null weights");
     DYGNN_REQUIRE(levels || (csr && csr->indptr && csr->num_nodes >= 1), "tgat: bad csr");
@@ -657,11 +662,11 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     // Distinct entries of level 1 are computed once (see k_dedup_insert): only when the library samples itself (`recent` is a function of
     // (node, time); pre-sampled random levels draw independently per entry) and the pair attention kernel, which knows the row map, applies.
-    const char* dd_env = getenv("DYGNN_TGAT_DEDUP");                 // "0" switches it off (read per call: the A/B switch of tests/test_tgat.py)
-    const bool dedup_on = !(dd_env && dd_env[0] == '0');
-    const bool dedup = dedup_on && !levels && p.L == 2 && p.k <= 20 && p.H <= 2 && p.Dkv <= 512;
+    const bool dedup = tgat_dedup_active(p, levels != nullptr);
 
-    if (levels) {
+    if (levels_in_workspace) {
+        // the caller ran this function's own expansion on this workspace already (TGN: it needs the level-0 node set before the features exist)
+    } else if (levels) {
         // pre-sampled levels (random strategies): copy them where the sampling kernels would have written them
         for (int l = 0; l <= p.L; ++l) {
             DYGNN_REQUIRE(levels->ids[l] && (l == 0 || (levels->nbr_eid[l] && levels->nbr_dt[l])), "tgat: null level array (level %d)", l);
@@ -697,6 +702,7 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
         }
     }
     }
+    if (expand_only) return DYGNN_OK;
     // bottom-up: layer l turns level-(l-1) embeddings (raw features for l = 1) into level-l embeddings
     const float scale = (float)pow((double)p.hd, -0.5);
     for (int l = 1; l <= p.L; ++l) {
@@ -749,27 +755,6 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
 // (MemoryModel.py:389-407) but its aggregator only ever reads the last element (:284-291), and lists are cleared
 // whole (:400-407), so the last message is the entire observable state.
 // ================================================================================================
-__global__ void k_tgn_gates(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ M, const float* __restrict__ raw,
-                            const int32_t* __restrict__ has_msg, int64_t N, int Fn, float* __restrict__ Mnew, float* __restrict__ feat0) {
-    // nn.GRUCell: r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * Fn) return;
-    const int64_t node = i / Fn;
-    const int f = (int)(i % Fn);
-    const float h = M[i];
-    float hn = h;
-    if (has_msg[node]) {
-        const float* a = gi + node * 3 * Fn;
-        const float* b = gh + node * 3 * Fn;
-        const float r = 1.0f / (1.0f + expf(-(a[f] + b[f])));
-        const float z = 1.0f / (1.0f + expf(-(a[Fn + f] + b[Fn + f])));
-        const float nn = tanhf(a[2 * Fn + f] + r * b[2 * Fn + f]);
-        hn = (1.0f - z) * nn + z * h;
-    }
-    Mnew[i] = hn;                                  // updated memories "just for computation" (MemoryModel.py:461-487)
-    feat0[i] = hn + raw[i];                        // layer-0 node features = memory + raw (MemoryModel.py:609)
-}
-
 // persist the update for the batch nodes that have a pending message and clear it (MemoryModel.py:142-145, :425-459)
 __global__ void k_tgn_persist(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t B, const float* __restrict__ Mnew,
                               const double* __restrict__ msg_t, int Fn, float* __restrict__ M, float* __restrict__ U, const int32_t* __restrict__ has_msg) {
@@ -817,7 +802,62 @@ __global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
     if (i < n) p[i] = v;
 }
 
-struct TgnPlan { size_t gi, gh, Mnew, feat0, win, tgat, total; };
+// ---- the nodes a call reads (TGN) --------------------------------------------------------------------------------------------
+// The reference updates the memory of every node with a pending message on every call (get_updated_memories over range(num_nodes),
+// MemoryModel.py:108-109) although a call only reads the rows of its level-0 set (roots and sampled neighbours).  Here the GRU runs
+// over exactly those: level-0 ids are marked in `flags`, marked nodes WITH a pending message are listed (their message / memory rows
+// are gathered, two GEMMs over the list, gates scattered back), marked nodes WITHOUT one get feat0 = memory + raw directly.  Rows
+// of a product do not depend on which other rows are in it, so every row read later is bit-identical to the all-nodes update.
+__global__ void k_mark_level0(const int32_t* __restrict__ ids0, int64_t n, int k, const int32_t* __restrict__ n_live, int64_t num_nodes,
+                              int32_t* __restrict__ flags) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (entry q, slot j): j = 0 the entry itself, 1..k its neighbours
+    const int64_t q = t / (k + 1);
+    const int j = (int)(t % (k + 1));
+    if (q >= n || (n_live && q >= *n_live)) return;
+    const int32_t id = j == 0 ? ids0[q] : ids0[n + q * k + (j - 1)];
+    if (id >= 0 && id < num_nodes) flags[id] = 1;
+}
+__global__ __launch_bounds__(256) void k_tgn_needed(const int32_t* __restrict__ flags, const int32_t* __restrict__ has_msg, const float* __restrict__ M,
+                                                     const float* __restrict__ raw, int64_t N, int Fn, int32_t* __restrict__ count,
+                                                     int32_t* __restrict__ list, float* __restrict__ feat0) {
+    const int lane = threadIdx.x & 63;
+    const int64_t node = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= N || !flags[node]) return;
+    if (has_msg[node]) {
+        if (lane == 0) list[atomicAdd(count, 1)] = (int32_t)node;
+    } else {
+        for (int f = lane; f < Fn; f += kWave) feat0[node * Fn + f] = M[node * Fn + f] + raw[node * Fn + f];      // memory + raw (MemoryModel.py:609)
+    }
+}
+__global__ __launch_bounds__(256) void k_tgn_gather(const int32_t* __restrict__ list, const int32_t* __restrict__ count, const float* __restrict__ msg,
+                                                     const float* __restrict__ M, int Dm, int Fn, float* __restrict__ amsg, float* __restrict__ amem) {
+    const int64_t r = blockIdx.x;
+    if (r >= *count) return;
+    const int64_t node = list[r];
+    for (int f = threadIdx.x; f < Dm; f += blockDim.x) amsg[r * Dm + f] = msg[node * Dm + f];
+    for (int f = threadIdx.x; f < Fn; f += blockDim.x) amem[r * Fn + f] = M[node * Fn + f];
+}
+__global__ void k_tgn_gates_list(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ M, const float* __restrict__ raw,
+                                 const int32_t* __restrict__ list, const int32_t* __restrict__ count, int Fn, float* __restrict__ Mnew,
+                                 float* __restrict__ feat0) {
+    // nn.GRUCell, as k_tgn_gates, for the listed nodes (row r of gi / gh belongs to node list[r])
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = i / Fn;
+    const int f = (int)(i % Fn);
+    if (r >= *count) return;
+    const int64_t node = list[r];
+    const float h = M[node * Fn + f];
+    const float* a = gi + r * 3 * Fn;
+    const float* b = gh + r * 3 * Fn;
+    const float rr = 1.0f / (1.0f + expf(-(a[f] + b[f])));
+    const float z = 1.0f / (1.0f + expf(-(a[Fn + f] + b[Fn + f])));
+    const float nn = tanhf(a[2 * Fn + f] + rr * b[2 * Fn + f]);
+    const float hn = (1.0f - z) * nn + z * h;
+    Mnew[node * Fn + f] = hn;
+    feat0[node * Fn + f] = hn + raw[node * Fn + f];
+}
+
+struct TgnPlan { size_t gi, gh, Mnew, feat0, win, tgat, flags, list, count, amsg, amem, total; };
 static TgnPlan make_tgn_plan(const dygnn_tgat_config& c, int64_t N, int64_t B) {
     TgnPlan p{};
     size_t o = 0;
@@ -827,6 +867,11 @@ static TgnPlan make_tgn_plan(const dygnn_tgat_config& c, int64_t N, int64_t B) {
     p.Mnew = take((size_t)N * c.node_feat_dim * sizeof(float));
     p.feat0 = take((size_t)N * c.node_feat_dim * sizeof(float));
     p.win = take((size_t)N * sizeof(int32_t));
+    p.flags = take((size_t)N * sizeof(int32_t));
+    p.list = take((size_t)N * sizeof(int32_t));
+    p.count = take(sizeof(int32_t));
+    p.amsg = take((size_t)N * (2 * c.node_feat_dim + c.time_feat_dim + c.edge_feat_dim) * sizeof(float));
+    p.amem = take((size_t)N * c.node_feat_dim * sizeof(float));
     p.tgat = take(make_tgat_plan(c, B).total);
     p.total = o;
     return p;
@@ -892,13 +937,35 @@ static int tgn_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weigh
     float* Mnew = reinterpret_cast<float*>(ws + p.Mnew);
     float* feat0 = reinterpret_cast<float*>(ws + p.feat0);
     int32_t* win = reinterpret_cast<int32_t*>(ws + p.win);
-    // 1. updated memories of ALL nodes (get_updated_memories over range(num_nodes), MemoryModel.py:108-109): two GEMMs + gates
-    if (int rc = gemm_nt<false>(st->msg, gru->weight_ih, gru->bias_ih, gi, N, 3 * Fn, Dm, 3 * Fn, s)) return rc;
-    if (int rc = gemm_nt<false>(st->memory, gru->weight_hh, gru->bias_hh, gh, N, 3 * Fn, Fn, 3 * Fn, s)) return rc;
-    hipLaunchKernelGGL(k_tgn_gates, dim3((unsigned)ceil_div(N * Fn, 256)), dim3(256), 0, s, gi, gh, st->memory, node_feat, st->has_msg, N, Fn, Mnew, feat0);
+    // 0. the levels of this call (they depend on the graph only): their level-0 set is what the call reads
+    char* wt = ws + p.tgat;
+    const size_t wt_bytes = p.total - p.tgat;
+    if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, wt, wt_bytes, stream, nullptr, false, true)) return rc;
+    const TgatPlan tp = make_tgat_plan(*cfg, batch);
+    const int32_t* live = tgat_dedup_active(tp, false) ? reinterpret_cast<const int32_t*>(wt + tp.dd_count) : nullptr;
+    int32_t* flags = reinterpret_cast<int32_t*>(ws + p.flags);
+    int32_t* list = reinterpret_cast<int32_t*>(ws + p.list);
+    int32_t* count = reinterpret_cast<int32_t*>(ws + p.count);
+    float* amsg = reinterpret_cast<float*>(ws + p.amsg);
+    float* amem = reinterpret_cast<float*>(ws + p.amem);
+    DYGNN_HIP(hipMemsetAsync(flags, 0, (size_t)N * sizeof(int32_t), s));
+    DYGNN_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_mark_level0, dim3((unsigned)ceil_div(tp.n[1] * (tp.k + 1), 256)), dim3(256), 0, s, reinterpret_cast<const int32_t*>(wt + tp.ids[0]), tp.n[1],
+                       tp.k, live, N, flags);
     DYGNN_LAUNCH_CHECK();
-    // 2. temporal graph attention over (memory + raw) features (GraphAttentionEmbedding, MemoryModel.py:548-664)
-    if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, ws + p.tgat, p.total - p.tgat, stream)) return rc;
+    // 1. updated memories of the nodes this call reads that have a pending message (the reference updates all nodes, MemoryModel.py:108-109;
+    //    see k_mark_level0): list them, gather their rows, two GEMMs over the list (row count on the device), gates scattered back
+    hipLaunchKernelGGL(k_tgn_needed, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, s, flags, st->has_msg, st->memory, node_feat, N, Fn, count, list, feat0);
+    DYGNN_LAUNCH_CHECK();
+    const int64_t ub = N < tp.n[0] ? N : tp.n[0];              // the list cannot be longer than the level-0 set
+    hipLaunchKernelGGL(k_tgn_gather, dim3((unsigned)ub), dim3(256), 0, s, list, count, st->msg, st->memory, Dm, Fn, amsg, amem);
+    DYGNN_LAUNCH_CHECK();
+    if (int rc = gemm_nt<false>(amsg, gru->weight_ih, gru->bias_ih, gi, ub, 3 * Fn, Dm, 3 * Fn, s, count)) return rc;
+    if (int rc = gemm_nt<false>(amem, gru->weight_hh, gru->bias_hh, gh, ub, 3 * Fn, Fn, 3 * Fn, s, count)) return rc;
+    hipLaunchKernelGGL(k_tgn_gates_list, dim3((unsigned)ceil_div(ub * Fn, 256)), dim3(256), 0, s, gi, gh, st->memory, node_feat, list, count, Fn, Mnew, feat0);
+    DYGNN_LAUNCH_CHECK();
+    // 2. temporal graph attention over (memory + raw) features (GraphAttentionEmbedding, MemoryModel.py:548-664) on the levels built above
+    if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, wt, wt_bytes, stream, nullptr, true)) return rc;
     if (!edges_are_positive) return DYGNN_OK;
     // 3. persist + clear for the batch nodes (MemoryModel.py:142-145)
     hipLaunchKernelGGL(k_tgn_persist, dim3((unsigned)(2 * n_pos)), dim3(64), 0, s, src, dst, n_pos, Mnew, st->msg_time, Fn, st->memory, st->last_update, st->has_msg);
