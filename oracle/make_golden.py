@@ -242,7 +242,7 @@ def run_eval_case(name: str) -> dict:
         c = gc.build_tgn_case(r["graph"]); cfg = c["tgn_cfg"]
     d = c["data"]
     ref_data = RefData(d.src_node_ids, d.dst_node_ids, d.node_interact_times, d.edge_ids, d.labels)
-    sampler = ref_get_neighbor_sampler(ref_data, sample_neighbor_strategy="recent", seed=1)
+    sampler = ref_get_neighbor_sampler(ref_data, sample_neighbor_strategy=r.get("strategy", "recent"), seed=r.get("sampler_seed", 1))
     if r["model"] == "DyGFormer":
         backbone = RefDyGFormer(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"],
                                 channel_embedding_dim=cfg["channel_embedding_dim"], patch_size=cfg["patch_size"], num_layers=cfg["num_layers"],

@@ -235,6 +235,8 @@ EVAL_CASES = {
     "eval_dygformer": dict(model="DyGFormer", graph="bip_p2_l64", batch=40),
     "eval_tgat": dict(model="TGAT", graph="tgat_bip_l2_k20", batch=40),
     "eval_tgn": dict(model="TGN", graph="tgn_bip_l1_k10", batch=40),
+    # random neighbour sampling: the sampler's RandomState is consumed call by call (positive call, then negative call, batch after batch)
+    "eval_tgat_uniform": dict(model="TGAT", graph="tgat_hub_l1_k10", batch=40, strategy="uniform", sampler_seed=3),
 }
 EVAL_FRACTION = 0.3
 EVAL_NEG_SEED = 0

@@ -60,7 +60,7 @@ def _build(name, dev):
     else:
         c = gc.build_tgn_case(r["graph"]); cfg = c["tgn_cfg"]
     d = c["data"]
-    sampler = get_neighbor_sampler(d, "recent", seed=1, device=dev)
+    sampler = get_neighbor_sampler(d, r.get("strategy", "recent"), seed=r.get("sampler_seed", 1), device=dev)
     if r["model"] == "DyGFormer":
         bb = DyGFormer(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"], channel_embedding_dim=cfg["channel_embedding_dim"],
                        patch_size=cfg["patch_size"], num_layers=cfg["num_layers"], num_heads=cfg["num_heads"], dropout=0.1,
