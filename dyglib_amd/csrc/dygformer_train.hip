@@ -9,6 +9,7 @@
 // (seed, site, element).  Gradients are produced for every parameter; the feature tables get none (the reference keeps
 // them as constants, models/DyGFormer.py:28-29).
 // This is the first, unfused version (correctness + a working training loop); inference uses dygformer_fused3.hip.
+#include <cstdlib>
 #include "dygformer_layout.h"
 #include "gemm.h"
 
@@ -239,6 +240,120 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same 64 x 64 tile product with both operands fed by LDS-DMA (global_load_lds: no VGPR round trip) into a ring of NS
+// stages of one 16-wide k-step each: NS - 1 steps of loads are in flight per workgroup instead of one, which is what the
+// latency-bound k-loop of k_mm_big lacks (its second register stage cost occupancy instead).  One barrier per k-step.
+// Tile of an operand in a stage: four 1-KiB blocks of 16 rows x 16 k, block w written by wave w with one DMA instruction
+// (lane L lands at byte 16 L of the block).  Lane -> element mapping per orientation, chosen so that the MFMA operand
+// reads (lane (c, g) needs row c, k = 4 kk + g) are conflict-free ds_read_b32:
+//   k-contiguous operand ([row][k] in memory): lane L loads the float4 (row = L & 15, k = 4 (L >> 4) ..+3)
+//       -> element (row c, k = 4 kk + g) sits at float 4 (16 kk + c) + g            (banks 4 c + g)
+//   row-contiguous operand ([k][row] in memory): lane L loads (k = 4 (L >> 4) + ((L >> 2) & 3), rows 4 (L & 3) ..+3)
+//       -> element (row c, k = 4 kk + g) sits at float 4 (16 kk + 4 g + (c >> 2)) + (c & 3)   (banks 16 g + c)
+// Rows / k beyond the matrix load from a 16-byte page of zeros (DMA cannot zero-fill), so tails need no special path as long
+// as a float4 never straddles a bound (K % 4 == 0, and M % 4 == 0 / N % 4 == 0 for a row-contiguous A / B: checked by mm()).
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int KA, int KB, int WM, int WN, int NS>      // KA / KB = 1: the operand is k-contiguous in memory (A: !transA, B: transB); tile 32 WM x 32 WN
+__global__ __launch_bounds__(256) void k_mm_dma(const MM p) {
+    constexpr int BM = 32 * WM, BN = 32 * WN, STAGE = 16 * (BM + BN);      // floats per stage: A tile then B tile
+    constexpr int LOADS = (WM + WN) / 2;                                    // DMA instructions per wave and stage
+    __shared__ __attribute__((aligned(16))) float ring[NS * STAGE];
+    const int z = blockIdx.z / p.ksplit, ks = blockIdx.z % p.ksplit, zb = z / p.H, zh = z % p.H;
+    const float* A = p.A + zb * p.sAb + zh * p.sAh;
+    const float* Bm = p.B + zb * p.sBb + zh * p.sBh;
+    float* C = p.C + zb * p.sCb + zh * p.sCh;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (p.m_dev && m0 >= *p.m_dev) return;
+    const int kbeg = ks * p.kchunk, kend = kbeg + p.kchunk < p.K ? kbeg + p.kchunk : p.K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wy = wave >> 1, wx = wave & 1, c = lane & 15, g = lane >> 4;
+    f4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    // this lane's source coordinates inside a 16-row block (wave w loads blocks w, w + 4, ...)
+    const int rA = KA ? (lane & 15) : 4 * (lane & 3), kA = KA ? 4 * (lane >> 4) : 4 * (lane >> 4) + ((lane >> 2) & 3);
+    const int rB = KB ? (lane & 15) : 4 * (lane & 3), kB = KB ? 4 * (lane >> 4) : 4 * (lane >> 4) + ((lane >> 2) & 3);
+    const int nsteps = (kend - kbeg + 15) >> 4;
+    auto issue = [&](int t) {                 // k-step t -> ring slot t % NS (beyond the last step: zeros, which keeps vmcnt uniform)
+        const int k0 = kbeg + 16 * t;
+        float* slot = ring + (t % NS) * STAGE;
+#pragma unroll
+        for (int u = 0; u < WM / 2; ++u) {
+            const int blk = wave + 4 * u, r = m0 + 16 * blk + rA;
+            const float* src = (t < nsteps && r < p.M && k0 + kA < kend) ? (KA ? A + (size_t)r * p.lda + k0 + kA : A + (size_t)(k0 + kA) * p.lda + r) : g_zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(slot + 256 * blk), 16, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < WN / 2; ++u) {
+            const int blk = wave + 4 * u, r = n0 + 16 * blk + rB;
+            const float* src = (t < nsteps && r < p.N && k0 + kB < kend) ? (KB ? Bm + (size_t)r * p.ldb + k0 + kB : Bm + (size_t)(k0 + kB) * p.ldb + r) : g_zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(slot + 16 * BM + 256 * blk), 16, 0, 0);
+        }
+    };
+    const bool want_colsum = p.colsum != nullptr && blockIdx.y == 0;      // only with a row-contiguous A (weight gradients), 64-row tiles
+    float csum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) issue(t);
+    for (int t = 0; t < nsteps; ++t) {
+        // this wave's loads of step t have landed; then a BARE barrier (everybody's have, and everybody is done with step t - 1):
+        // __syncthreads() would add a fence = s_waitcnt vmcnt(0), i.e. wait for the whole ring and undo the pipelining
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LOADS * (NS - 2)) : "memory");
+        issue(t + NS - 1);                                                      // into the slot step t - 1 used
+        const float* as = ring + (t % NS) * STAGE;
+        const float* bs = as + 16 * BM;
+        if (!KA && WM == 2 && want_colsum) {  // element (row = lane, k) of the A tile: block lane >> 4, row c; this wave sums k = 4 wave .. +3
+            const float* q = as + 256 * g + 4 * (16 * wave + (c >> 2)) + (c & 3);
+            csum += (q[0] + q[16]) + (q[32] + q[48]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float a[WM], b[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a[i] = KA ? as[256 * (WM * wy + i) + 4 * (16 * kk + c) + g] : as[256 * (WM * wy + i) + 4 * (16 * kk + 4 * g + (c >> 2)) + (c & 3)];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b[j] = KB ? bs[256 * (WN * wx + j) + 4 * (16 * kk + c) + g] : bs[256 * (WN * wx + j) + 4 * (16 * kk + 4 * g + (c >> 2)) + (c & 3)];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing zero-page loads must not outlive the workgroup's LDS
+    if (WM == 2 && want_colsum && m0 + lane < p.M) atomicAdd(&p.colsum[m0 + lane], csum);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + 16 * WN * wx + 16 * j + c;
+        if (n >= p.N) continue;
+        const float bv = (p.bias && ks == 0) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * WM * wy + 16 * i + 4 * g + r;
+                if (m >= p.M) continue;
+                float v = p.alpha * acc[i][j][r] + bv;
+                if (p.ksplit > 1) { atomicAdd(&C[(size_t)m * p.ldc + n], v); continue; }
+                if (p.beta != 0.f) v += p.beta * C[(size_t)m * p.ldc + n];
+                if (p.relu) v = fmaxf(v, 0.f);
+                C[(size_t)m * p.ldc + n] = v;
+            }
+    }
+}
+
+template <int WM, int WN, int NS>
+static void launch_mm_dma(hipStream_t s, const MM& p, bool tA, bool tB, int batch) {
+    const dim3 grid((unsigned)ceil_div(p.M, 32 * WM), (unsigned)ceil_div(p.N, 32 * WN), (unsigned)batch);
+    if (!tA && tB) hipLaunchKernelGGL((k_mm_dma<1, 1, WM, WN, NS>), grid, dim3(256), 0, s, p);
+    else if (!tA && !tB) hipLaunchKernelGGL((k_mm_dma<1, 0, WM, WN, NS>), grid, dim3(256), 0, s, p);
+    else if (tA && !tB) hipLaunchKernelGGL((k_mm_dma<0, 0, WM, WN, NS>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_mm_dma<0, 1, WM, WN, NS>), grid, dim3(256), 0, s, p);
+}
+
 static int colsum(hipStream_t s, const float* A, int lda, int64_t M, int N, float* out, bool accumulate = false);
 
 int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb, bool tB, float* C, int ldc, int M, int N, int K, const float* bias, float alpha,
@@ -264,6 +379,14 @@ int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb,
         //  * 64-row tiles always: the k-loop is latency-bound (one global -> LDS hop per 16-wide k-step), so what pays is more resident
         //    workgroups per CU, not more MFMAs per LDS read; 128-row tiles were slower at every size (TGAT -7 %, training -5 %);
         //  * 64-column tiles unless 128-column tiles pad clearly less (N = 272 pads to 320 instead of 384): TGN +38 %, TGAT +14 %.
+        // both operands by LDS-DMA when no float4 can straddle a bound (see k_mm_dma)
+        const char* dma_env = getenv("DYGNN_MM_DMA");
+        if (vecA && vecB && K % 4 == 0 && (!tA || M % 4 == 0) && (tB || N % 4 == 0) && !(dma_env && dma_env[0] == '0')) {
+            // measured: 64 x 64 tiles with a 4-stage ring; 3 stages tie, 6 / 8 stages and 128 x 128 tiles (3 stages) lose occupancy and are slower
+            launch_mm_dma<2, 2, 4>(s, p, tA, tB, batch);
+            DYGNN_LAUNCH_CHECK();
+            return DYGNN_OK;
+        }
         const double w64 = (double)(ceil_div(N, 64) * 64) / N, w128 = (double)(ceil_div(N, 128) * 128) / N;
         if (N <= 64 || w64 * 0.95 < w128)
             hipLaunchKernelGGL((k_mm_big<2, 2>), dim3((unsigned)ceil_div(M, 64), (unsigned)ceil_div(N, 64), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
