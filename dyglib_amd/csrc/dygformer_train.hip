@@ -310,6 +310,22 @@ __global__ __launch_bounds__(256) void k_mm_dma(const MM p) {
             const float* q = as + 256 * g + 4 * (16 * wave + (c >> 2)) + (c & 3);
             csum += (q[0] + q[16]) + (q[32] + q[48]);
         }
+        if constexpr (KA && KB) {
+            // both operands k-contiguous: lane (c, g) takes the whole float4 granule (row c, k = 4 g ..+3) with ONE conflict-free
+            // ds_read_b128 per tile (ds_read_b32 of this layout is 2-way conflicted: its banks are (a/4) mod 32 per half-wave),
+            // and MFMA step r multiplies k = 4 g + r of both operands -- the same permutation of k on both sides
+            f4 a4[WM], b4[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a4[i] = *reinterpret_cast<const f4*>(as + 256 * (WM * wy + i) + 4 * (16 * g + c));
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b4[j] = *reinterpret_cast<const f4*>(bs + 256 * (WN * wx + j) + 4 * (16 * g + c));
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i][r], b4[j][r], acc[i][j], 0, 0, 0);
+        } else
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             float a[WM], b[WN];
