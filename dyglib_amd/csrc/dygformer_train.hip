@@ -246,11 +246,11 @@ __global__ __launch_bounds__(256) void k_mm_big(const MM p, const int vecA, cons
 // latency-bound k-loop of k_mm_big lacks (its second register stage cost occupancy instead).  One barrier per k-step.
 // Tile of an operand in a stage: four 1-KiB blocks of 16 rows x 16 k, block w written by wave w with one DMA instruction
 // (lane L lands at byte 16 L of the block).  Lane -> element mapping per orientation, chosen so that the MFMA operand
-// reads (lane (c, g) needs row c, k = 4 kk + g) are conflict-free ds_read_b32:
+// reads are conflict-free in the PERMUTED k order (MFMA step r takes k = 4 g + r from both operands):
 //   k-contiguous operand ([row][k] in memory): lane L loads the float4 (row = L & 15, k = 4 (L >> 4) ..+3)
-//       -> element (row c, k = 4 kk + g) sits at float 4 (16 kk + c) + g            (banks 4 c + g)
-//   row-contiguous operand ([k][row] in memory): lane L loads (k = 4 (L >> 4) + ((L >> 2) & 3), rows 4 (L & 3) ..+3)
-//       -> element (row c, k = 4 kk + g) sits at float 4 (16 kk + 4 g + (c >> 2)) + (c & 3)   (banks 16 g + c)
+//       -> lane (c, g) reads the granule at float 4 (16 g + c) with one ds_read_b128
+//   row-contiguous operand ([k][row] in memory): lane L loads (k = 4 ((L >> 2) & 3) + (L >> 4), rows 4 (L & 3) ..+3)
+//       -> element (row c, k = 4 g + r) sits at float 4 (16 r + 4 g + (c >> 2)) + (c & 3)     (banks 16 g + c per half-wave)
 // Rows / k beyond the matrix load from a 16-byte page of zeros (DMA cannot zero-fill), so tails need no special path as long
 // as a float4 never straddles a bound (K % 4 == 0, and M % 4 == 0 / N % 4 == 0 for a row-contiguous A / B: checked by mm()).
 // ------------------------------------------------------------------------------------------------
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(256) void k_mm_dma(const MM p) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     // this lane's source coordinates inside a 16-row block (wave w loads blocks w, w + 4, ...)
-    const int rA = KA ? (lane & 15) : 4 * (lane & 3), kA = KA ? 4 * (lane >> 4) : 4 * (lane >> 4) + ((lane >> 2) & 3);
-    const int rB = KB ? (lane & 15) : 4 * (lane & 3), kB = KB ? 4 * (lane >> 4) : 4 * (lane >> 4) + ((lane >> 2) & 3);
+    const int rA = KA ? (lane & 15) : 4 * (lane & 3), kA = KA ? 4 * (lane >> 4) : 4 * ((lane >> 2) & 3) + (lane >> 4);
+    const int rB = KB ? (lane & 15) : 4 * (lane & 3), kB = KB ? 4 * (lane >> 4) : 4 * ((lane >> 2) & 3) + (lane >> 4);
     const int nsteps = (kend - kbeg + 15) >> 4;
     auto issue = [&](int t) {                 // k-step t -> ring slot t % NS (beyond the last step: zeros, which keeps vmcnt uniform)
         const int k0 = kbeg + 16 * t;
@@ -310,34 +310,37 @@ __global__ __launch_bounds__(256) void k_mm_dma(const MM p) {
             const float* q = as + 256 * g + 4 * (16 * wave + (c >> 2)) + (c & 3);
             csum += (q[0] + q[16]) + (q[32] + q[48]);
         }
-        if constexpr (KA && KB) {
-            // both operands k-contiguous: lane (c, g) takes the whole float4 granule (row c, k = 4 g ..+3) with ONE conflict-free
-            // ds_read_b128 per tile (ds_read_b32 of this layout is 2-way conflicted: its banks are (a/4) mod 32 per half-wave),
-            // and MFMA step r multiplies k = 4 g + r of both operands -- the same permutation of k on both sides
-            f4 a4[WM], b4[WN];
+        // Permuted k order: MFMA step r multiplies k = 4 g + r of both operands.  A k-contiguous operand then needs ONE conflict-free
+        // ds_read_b128 per tile (lane (c, g) takes the whole granule of row c; ds_read_b32 of that layout would be 2-way conflicted,
+        // its banks being (a/4) mod 32 per half-wave); a row-contiguous operand reads element (row c, k = 4 g + r) at float
+        // 4 (16 r + 4 g + (c >> 2)) + (c & 3): banks 16 g + c inside a half-wave, conflict-free.
+        float a[WM][4], b[WN][4];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a4[i] = *reinterpret_cast<const f4*>(as + 256 * (WM * wy + i) + 4 * (16 * g + c));
+        for (int i = 0; i < WM; ++i) {
+            if constexpr (KA) {
+                const f4 v = *reinterpret_cast<const f4*>(as + 256 * (WM * wy + i) + 4 * (16 * g + c));
+                a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+            } else {
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b4[j] = *reinterpret_cast<const f4*>(bs + 256 * (WN * wx + j) + 4 * (16 * g + c));
+                for (int r = 0; r < 4; ++r) a[i][r] = as[256 * (WM * wy + i) + 4 * (16 * r + 4 * g + (c >> 2)) + (c & 3)];
+            }
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+        for (int j = 0; j < WN; ++j) {
+            if constexpr (KB) {
+                const f4 v = *reinterpret_cast<const f4*>(bs + 256 * (WN * wx + j) + 4 * (16 * g + c));
+                b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+            } else {
 #pragma unroll
-                for (int i = 0; i < WM; ++i)
+                for (int r = 0; r < 4; ++r) b[j][r] = bs[256 * (WN * wx + j) + 4 * (16 * r + 4 * g + (c >> 2)) + (c & 3)];
+            }
+        }
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i][r], b4[j][r], acc[i][j], 0, 0, 0);
-        } else
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            float a[WM], b[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = KA ? as[256 * (WM * wy + i) + 4 * (16 * kk + c) + g] : as[256 * (WM * wy + i) + 4 * (16 * kk + 4 * g + (c >> 2)) + (c & 3)];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = KB ? bs[256 * (WN * wx + j) + 4 * (16 * kk + c) + g] : bs[256 * (WN * wx + j) + 4 * (16 * kk + 4 * g + (c >> 2)) + (c & 3)];
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][r], b[j][r], acc[i][j], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing zero-page loads must not outlive the workgroup's LDS
     if (WM == 2 && want_colsum && m0 + lane < p.M) atomicAdd(&p.colsum[m0 + lane], csum);
