@@ -36,6 +36,7 @@ struct MM {
     int ksplit, kchunk;     // split-K: blockIdx.z = batch * ksplit + part; part sums k in [part*kchunk, +kchunk) and adds atomically
     float* colsum;          // transA products only: colsum[m] += sum_k op(A)[m][k] (the bias gradient next to a weight gradient), or null
     const int32_t* m_dev;   // optional device-side row count (<= M): workgroups whose rows all lie beyond it exit at once
+    int vecC;               // C rows may be written as aligned float4 (pointer, ldc and batch strides multiples of 4 floats)
 };
 
 __global__ __launch_bounds__(256) void k_mm(const MM p) {
@@ -344,6 +345,41 @@ __global__ __launch_bounds__(256) void k_mm_dma(const MM p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing zero-page loads must not outlive the workgroup's LDS
     if (WM == 2 && want_colsum && m0 + lane < p.M) atomicAdd(&p.colsum[m0 + lane], csum);
+    if (WM == 2 && WN == 2 && p.vecC && p.ksplit == 1 && p.beta == 0.f) {
+        // coalesced epilogue: the tile goes through LDS (the ring is free now) and leaves as float4 rows -- 16 lanes write one 256-byte
+        // row segment, 4 store instructions per wave instead of 16 scalar ones that each touch four rows
+        asm volatile("s_barrier" ::: "memory");                   // every wave is done reading the ring
+        constexpr int LD = 64 + 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nl = 32 * wx + 16 * j + c;
+            const float bv = (p.bias && n0 + nl < p.N) ? p.bias[n0 + nl] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = p.alpha * acc[i][j][r] + bv;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    ring[(32 * wy + 16 * i + 4 * g + r) * LD + nl] = v;
+                }
+        }
+        __syncthreads();
+        const int col = 4 * (tid & 15);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = 16 * ps + (tid >> 4), m = m0 + row, n = n0 + col;
+            if (m >= p.M || n >= p.N) continue;
+            const f4 v = *reinterpret_cast<const f4*>(ring + row * LD + col);
+            float* dst = C + (size_t)m * p.ldc + n;
+            if (n + 3 < p.N) *reinterpret_cast<f4*>(dst) = v;
+            else {
+                dst[0] = v.x;
+                if (n + 1 < p.N) dst[1] = v.y;
+                if (n + 2 < p.N) dst[2] = v.z;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int n = n0 + 16 * WN * wx + 16 * j + c;
@@ -378,7 +414,8 @@ static int colsum(hipStream_t s, const float* A, int lda, int64_t M, int N, floa
 int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb, bool tB, float* C, int ldc, int M, int N, int K, const float* bias, float alpha,
        float beta, int batch, int H, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, bool relu, bool c_is_zero, float* colsum_out, const int32_t* m_dev) {
     if (M <= 0 || N <= 0 || batch <= 0) return DYGNN_OK;
-    MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh, relu ? 1 : 0, 1, K, nullptr, m_dev};
+    MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh, relu ? 1 : 0, 1, K, nullptr, m_dev,
+         ((reinterpret_cast<uintptr_t>(C) & 15) == 0 && ldc % 4 == 0 && sCb % 4 == 0 && sCh % 4 == 0) ? 1 : 0};
     if (colsum_out) {                 // rides along inside the 64-row-tile kernel; anything else gets the stand-alone reduction
         if (tA && batch == 1 && M >= 48 && N >= 48) p.colsum = colsum_out;
         else if (int rc = colsum(s, A, lda, K, M, colsum_out)) return rc;
