@@ -755,35 +755,38 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
 // (MemoryModel.py:389-407) but its aggregator only ever reads the last element (:284-291), and lists are cleared
 // whole (:400-407), so the last message is the entire observable state.
 // ================================================================================================
-// persist the update for the batch nodes that have a pending message and clear it (MemoryModel.py:142-145, :425-459)
-__global__ void k_tgn_persist(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t B, const float* __restrict__ Mnew,
-                              const double* __restrict__ msg_t, int Fn, float* __restrict__ M, float* __restrict__ U, const int32_t* __restrict__ has_msg) {
-    const int64_t r = blockIdx.x;                  // 0..2B-1 (a node occurring several times is written several times with the same values)
+// persist the update for the batch nodes that have a pending message and clear it (MemoryModel.py:142-145, :425-459).  A node that
+// occurs several times is handled by several workgroups: each either still sees the flag and writes the same values, or sees it cleared
+__global__ void k_tgn_persist_clear(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t B, const float* __restrict__ Mnew,
+                                    const double* __restrict__ msg_t, int Fn, float* __restrict__ M, float* __restrict__ U, int32_t* __restrict__ has_msg) {
+    const int64_t r = blockIdx.x;                  // 0..2B-1
     const int64_t node = r < B ? src[r] : dst[r - B];
-    if (has_msg[node]) {
+    const bool pending = has_msg[node] != 0;       // the same for every thread of the workgroup unless a twin clears it meanwhile: harmless
+    if (pending) {
         for (int f = threadIdx.x; f < Fn; f += blockDim.x) M[node * Fn + f] = Mnew[node * Fn + f];
         if (threadIdx.x == 0) U[node] = (float)msg_t[node];
     }
+    __syncthreads();
+    if (threadIdx.x == 0) has_msg[node] = 0;
 }
-__global__ void k_tgn_clear(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t B, int32_t* __restrict__ has_msg) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < 2 * B) has_msg[r < B ? src[r] : dst[r - B]] = 0;
+// Messages are stored source role first, then destination role (MemoryModel.py:147-161), and only a node's LAST stored message is ever
+// read (:284-291): entry e = role * B + i (role 0 = source), the winner of a node is its largest e
+__global__ void k_tgn_winner(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t B, int32_t* __restrict__ win) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 2 * B) atomicMax(&win[e < B ? src[e] : dst[e - B]], (int32_t)e);
 }
-// winner per node for one role = the LAST occurrence in batch order (list append order, MemoryModel.py:244-249)
-__global__ void k_tgn_winner(const int64_t* __restrict__ who, int64_t B, int32_t* __restrict__ win) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) atomicMax(&win[who[i]], (int32_t)i);
-}
-// new raw message of role-node who[i]: [M[who] | M[other] | cos(w (t - U[who]) + b) | edge feature]  (MemoryModel.py:223-241)
-__global__ __launch_bounds__(256) void k_tgn_message(const int64_t* __restrict__ who, const int64_t* __restrict__ other, const double* __restrict__ times,
+// new raw message of the role-node of entry e: [M[who] | M[other] | cos(w (t - U[who]) + b) | edge feature]  (MemoryModel.py:223-241)
+__global__ __launch_bounds__(256) void k_tgn_message(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const double* __restrict__ times,
                                                        const int64_t* __restrict__ eids, int64_t B, const float* __restrict__ M, const float* __restrict__ U,
                                                        const float* __restrict__ edge_feat, const float* __restrict__ tw, const float* __restrict__ tb,
                                                        int Fn, int Fe, int Ft, const int32_t* __restrict__ win, float* __restrict__ msg,
                                                        double* __restrict__ msg_t, int32_t* __restrict__ has_msg) {
-    const int64_t i = blockIdx.x;
-    const int64_t node = who[i];
-    if (win[node] != (int32_t)i) return;           // only the last occurrence is observable
-    const int64_t o = other[i];
+    const int64_t e = blockIdx.x;
+    const bool role = e >= B;
+    const int64_t i = role ? e - B : e;
+    const int64_t node = role ? dst[i] : src[i];
+    if (win[node] != (int32_t)e) return;           // only the last stored message is observable
+    const int64_t o = role ? src[i] : dst[i];
     const int D = 2 * Fn + Ft + Fe;
     const float dt = (float)times[i] - U[node];    // float32 - float32 (MemoryModel.py:232-233)
     float* m = msg + node * D;
@@ -968,22 +971,16 @@ static int tgn_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weigh
     if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, wt, wt_bytes, stream, nullptr, true)) return rc;
     if (!edges_are_positive) return DYGNN_OK;
     // 3. persist + clear for the batch nodes (MemoryModel.py:142-145)
-    hipLaunchKernelGGL(k_tgn_persist, dim3((unsigned)(2 * n_pos)), dim3(64), 0, s, src, dst, n_pos, Mnew, st->msg_time, Fn, st->memory, st->last_update, st->has_msg);
+    hipLaunchKernelGGL(k_tgn_persist_clear, dim3((unsigned)(2 * n_pos)), dim3(64), 0, s, src, dst, n_pos, Mnew, st->msg_time, Fn, st->memory, st->last_update, st->has_msg);
     DYGNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_tgn_clear, dim3((unsigned)ceil_div(2 * n_pos, 256)), dim3(256), 0, s, src, dst, n_pos, st->has_msg);
+    // 4. new raw messages of both roles (one winner pass, one message pass)
+    hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, win, N, -1);
     DYGNN_LAUNCH_CHECK();
-    // 4. new raw messages: source role first, then destination role (store order, MemoryModel.py:147-161)
-    for (int role = 0; role < 2; ++role) {
-        const int64_t* who = role ? dst : src;
-        const int64_t* other = role ? src : dst;
-        hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, win, N, -1);
-        DYGNN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_tgn_winner, dim3((unsigned)ceil_div(n_pos, 256)), dim3(256), 0, s, who, n_pos, win);
-        DYGNN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_tgn_message, dim3((unsigned)n_pos), dim3(256), 0, s, who, other, times, edge_ids, n_pos, st->memory, st->last_update, edge_feat,
-                           w->time_w, w->time_b, Fn, Fe, Ft, win, st->msg, st->msg_time, st->has_msg);
-        DYGNN_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(k_tgn_winner, dim3((unsigned)ceil_div(2 * n_pos, 256)), dim3(256), 0, s, src, dst, n_pos, win);
+    DYGNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_tgn_message, dim3((unsigned)(2 * n_pos)), dim3(256), 0, s, src, dst, times, edge_ids, n_pos, st->memory, st->last_update, edge_feat,
+                       w->time_w, w->time_b, Fn, Fe, Ft, win, st->msg, st->msg_time, st->has_msg);
+    DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }
 
