@@ -740,7 +740,10 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
                            n, p.Dq, p.Fn, F32(p.merge_in), nl);
         DYGNN_LAUNCH_CHECK();
         if (int rc = gemm_nt<true>(F32(p.merge_in), Lw.fc1_w, Lw.fc1_b, F32(p.hid), n, p.Fn, p.Dq + p.Fn, p.Fn, s, nl)) return rc;
-        if (int rc = gemm_nt<false>(F32(p.hid), Lw.fc2_w, Lw.fc2_b, F32(p.h[l]), n, p.Fn, p.Fn, p.Fn, s, nl)) return rc;
+        // the top level is [src rows ; dst rows]: when the caller's two outputs are one [2B, Fn] block it is written in place
+        const bool direct = l == p.L && out_dst == out_src + (size_t)batch * p.Fn;
+        if (int rc = gemm_nt<false>(F32(p.hid), Lw.fc2_w, Lw.fc2_b, direct ? out_src : F32(p.h[l]), n, p.Fn, p.Fn, p.Fn, s, nl)) return rc;
+        if (direct) return DYGNN_OK;
     }
     hipLaunchKernelGGL(k_split_out, dim3((unsigned)ceil_div(2 * batch * p.Fn, 256)), dim3(256), 0, s, F32(p.h[p.L]), batch, p.Fn, out_src, out_dst);
     DYGNN_LAUNCH_CHECK();
@@ -870,9 +873,9 @@ static TgnPlan make_tgn_plan(const dygnn_tgat_config& c, int64_t N, int64_t B) {
     p.Mnew = take((size_t)N * c.node_feat_dim * sizeof(float));
     p.feat0 = take((size_t)N * c.node_feat_dim * sizeof(float));
     p.win = take((size_t)N * sizeof(int32_t));
-    p.flags = take((size_t)N * sizeof(int32_t));
+    p.flags = take((size_t)(N + 1) * sizeof(int32_t));       // [N] flags, then the list length (one memset clears both)
+    p.count = p.flags + (size_t)N * sizeof(int32_t);
     p.list = take((size_t)N * sizeof(int32_t));
-    p.count = take(sizeof(int32_t));
     p.amsg = take((size_t)N * (2 * c.node_feat_dim + c.time_feat_dim + c.edge_feat_dim) * sizeof(float));
     p.amem = take((size_t)N * c.node_feat_dim * sizeof(float));
     p.tgat = take(make_tgat_plan(c, B).total);
@@ -951,8 +954,7 @@ static int tgn_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weigh
     int32_t* count = reinterpret_cast<int32_t*>(ws + p.count);
     float* amsg = reinterpret_cast<float*>(ws + p.amsg);
     float* amem = reinterpret_cast<float*>(ws + p.amem);
-    DYGNN_HIP(hipMemsetAsync(flags, 0, (size_t)N * sizeof(int32_t), s));
-    DYGNN_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+    DYGNN_HIP(hipMemsetAsync(flags, 0, (size_t)(N + 1) * sizeof(int32_t), s));      // flags and, right behind them, the list length
     hipLaunchKernelGGL(k_mark_level0, dim3((unsigned)ceil_div(tp.n[1] * (tp.k + 1), 256)), dim3(256), 0, s, reinterpret_cast<const int32_t*>(wt + tp.ids[0]), tp.n[1],
                        tp.k, live, N, flags);
     DYGNN_LAUNCH_CHECK();

@@ -155,8 +155,8 @@ class MemoryModel(nn.Module):
         if edges_are_positive:
             assert edge_ids is not None                                                        # MemoryModel.py:140
         eids = to_dev(edge_ids, torch.int64) if edge_ids is not None else None
-        out_src = torch.empty((B, self.node_feat_dim), dtype=torch.float32, device=dev)
-        out_dst = torch.empty_like(out_src)
+        out = torch.empty((2, B, self.node_feat_dim), dtype=torch.float32, device=dev)      # one block: the library writes it in place
+        out_src, out_dst = out[0], out[1]
         if B == 0:
             return out_src, out_dst
         cfg = _capi.TgatConfig(self.node_feat_dim, self.edge_feat_dim, self.time_feat_dim, self.num_layers, self.num_heads, int(num_neighbors))

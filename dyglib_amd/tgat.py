@@ -82,8 +82,8 @@ class TGAT(nn.Module):
         src, dst, tms = to_dev(src_node_ids, torch.int64), to_dev(dst_node_ids, torch.int64), to_dev(node_interact_times, torch.float64)
         B = src.numel()
         assert dst.numel() == B and tms.numel() == B
-        out_src = torch.empty((B, self.node_feat_dim), dtype=torch.float32, device=dev)
-        out_dst = torch.empty_like(out_src)
+        out = torch.empty((2, B, self.node_feat_dim), dtype=torch.float32, device=dev)      # one block: the library writes it in place
+        out_src, out_dst = out[0], out[1]
         if B == 0:
             return out_src, out_dst
         cfg = _capi.TgatConfig(self.node_feat_dim, self.edge_feat_dim, self.time_feat_dim, self.num_layers, self.num_heads, int(num_neighbors))
