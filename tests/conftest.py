@@ -31,3 +31,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    # the margin of every floating-point parity comparison of this run (tests/parity.py)
+    from tests import parity
+    if not parity.OBSERVED:
+        return
+    tr = terminalreporter
+    tr.write_sep("-", "observed floating-point parity errors (max over the run; bar 1e-4)")
+    for label in sorted(parity.OBSERVED):
+        err, refmax, atol = parity.OBSERVED[label]
+        tr.write_line(f"{label:70s} max|err| {err:9.3e}   max|ref| {refmax:9.3g}   tol {atol:8.1e}")

@@ -1,8 +1,9 @@
 """GPU parity of DyGFormer.compute_src_dst_node_temporal_embeddings through the C ABI.
 
 Tolerance: BASELINE.json's north_star asks for fp32 embeddings within 1e-4 of the reference CPU
-path.  Every comparison below uses atol = 1e-4 * max(1, max|reference|) (the L=512 stress case has
-embeddings of magnitude ~20, where 1e-4 absolute would be below fp32 resolution of the sums)."""
+path.  Every comparison below is a plain absolute 1e-4 (tests/parity.py), also on the L=512 stress
+case whose embeddings reach magnitude ~20; the largest observed error per label is printed at the
+end of the run."""
 import numpy as np
 import pytest
 import torch
@@ -10,6 +11,7 @@ import torch
 from dyglib_amd import synthetic as syn
 from oracle import dygformer_oracle as orc
 from tests import golden_cases as gc
+from tests.parity import close  # plain 1e-4 absolute; observed errors are printed at the end of the run
 
 pytestmark = pytest.mark.gpu
 
@@ -19,15 +21,6 @@ FUSED_UNSUPPORTED = {"bip_p8_l512", "bip_p64_l2048"}      # impl 2 (wave-pair ke
 GENERIC_UNSUPPORTED = {"bip_p64_l2048"}                   # impl 1: 4096 window positions do not fit its LDS staging
 
 
-def close(got, want, what=""):
-    want = np.asarray(want)
-    got = np.asarray(got)
-    assert got.shape == want.shape, (what, got.shape, want.shape)
-    atol = TOL * max(1.0, float(np.abs(want).max()))
-    err = float(np.abs(got - want).max())
-    assert np.isfinite(got).all(), what
-    assert err <= atol, f"{what}: max abs err {err:.3e} > {atol:.3e}"
-    return err
 
 
 def build_model(c, device="cuda:0"):

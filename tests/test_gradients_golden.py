@@ -9,6 +9,7 @@ import torch
 
 from oracle import dygformer_oracle as orc
 from tests import golden_cases as gc
+from tests.parity import close_scaled
 
 TOL = 1e-4
 
@@ -18,8 +19,7 @@ def _check(name, grads: dict, g: dict):
         got = np.asarray(got)
         if f"{k}|full" in g:
             ref = g[f"{k}|full"]
-            tol = TOL * max(1.0, float(np.abs(ref).max()))
-            assert np.abs(got - ref).max() <= tol, (name, k, float(np.abs(got - ref).max()), tol)
+            close_scaled(got, ref, f"{name} grad {k}", label=f"gradients vs reference autograd, {name} (worst full tensor, scaled bar)")
         else:
             absmax = float(g[f"{k}|absmax"])
             tol = TOL * max(1.0, absmax)

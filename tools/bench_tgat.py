@@ -1,67 +1,13 @@
 #!/usr/bin/env python3
-"""Secondary benchmark (BASELINE config 3): TGAT link-prediction forward, Reddit-shaped synthetic graph
-(10,000 + 984 nodes, 672,447 edges), k = 20, 2 layers, batch 200: pos call + neg call + MergeLayer+sigmoid per step.
-Prints one JSON line (same fields as bench.py; not the headline metric)."""
-import argparse, json, os, sys, time
-import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-from dyglib_amd import TGAT, MergeLayer, get_neighbor_sampler, synthetic as syn
+"""Secondary benchmark (BASELINE config 3): TGAT on the Reddit-shaped synthetic graph.  The workload lives in bench.py
+(`bench_tgat`, also run as part of `python bench.py` -> secondary.tgat); this is its stand-alone command line.  One JSON line."""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=3)
-ap.add_argument("--edges", type=int, default=672447); ap.add_argument("--cpu-steps", type=int, default=2)
-ap.add_argument("--fuse-steps", type=int, default=32, help="evaluation steps per call: TGAT rows do not depend on the batch they are in (fixed k, no "
-                "batch-dependent padding), so F steps are one call on F*200 edges and every row equals the row of the single-step call")
-args = ap.parse_args()
-dev = "cuda:0"
-B, K = 200, 20
-data, nf, ef = syn.make_bipartite_graph(10000, 984, args.edges, seed=0)
-params, mparams = syn.make_tgat_params(0), syn.make_merge_layer_params(1000)
-sampler = get_neighbor_sampler(data, "recent", seed=1, device=dev)
-model = TGAT(nf, ef, sampler, 100, num_layers=2, num_heads=2, dropout=0.1, device=dev)
-model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
-merge = MergeLayer(172, 172, 172, 1); merge.load_state_dict({k: torch.from_numpy(v) for k, v in mparams.items()})
-model, merge = model.to(dev).eval(), merge.to(dev).eval()
-E = data.num_interactions; first = int(E * 0.7); nb = (E - first) // B
-rs = np.random.RandomState(2); ud = np.unique(data.dst_node_ids)
-batches = []
-F = max(1, args.fuse_steps)
-steps = (args.steps + F - 1) // F * F
-for i in range(min(nb // F, (steps + args.warmup * F) // F)):
-    sl = slice(first + i * B * F, first + (i + 1) * B * F)
-    batches.append(tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in
-                         (data.src_node_ids[sl], data.dst_node_ids[sl], syn.random_negative_dst(rs, ud, B * F), data.node_interact_times[sl])))
-def step(i):
-    s, d, n, t = batches[i % len(batches)]
-    with torch.no_grad():
-        # the positive and the negative call as ONE call on [pos ; neg] (rows do not depend on the batch they are in): the shared
-        # source side and every other repeated (node, time) entry of level 1 is then computed once (level de-duplication, tgat.hip)
-        a, b_ = model.compute_src_dst_node_temporal_embeddings(torch.cat([s, s]), torch.cat([d, n]), torch.cat([t, t]), num_neighbors=K)
-        p = merge.link_probabilities(a, b_)
-        return p[:len(s)], p[len(s):]
-for i in range(args.warmup): step(i)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for i in range(steps // F): step(args.warmup + i)
-torch.cuda.synchronize(); el = time.perf_counter() - t0
-args.steps = steps
-out = {"metric": "edges/sec (link-prediction fwd) TGAT Reddit-shaped", "value": round(args.steps * B / el, 1), "unit": "edges/s",
-       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "dtype": "f32", "data": "synthetic",
-       "config": {"workload": f"TGAT link-prediction forward, synthetic Reddit-shaped graph (10000+984 nodes, {args.edges} edges), k=20, 2 layers, batch=200", "fuse_steps": F},
-       }
-# executed work: 1.062 MFLOP per COMPUTED (node, time) entry (q 2*272^2 + W_k^T q 2*2*136*444 + W_v z 2*2*444*136 + residual_fc 2*272^2 + merge fc1
-# 2*444*172 + fc2 2*172^2 + scores and weighted sums 2*2*20*444*2; K/V never materialised).  The reference computes
-# 2*2*200*(1+21) = 17,600 entries per step at 10.19 MFLOP each (179.4 GFLOP per step); here duplicates of level 1 are computed once.
-total_entries, computed_entries = model.last_level_entries()          # of the last call (F steps, positive and negative together)
-per_step = computed_entries / F
-sec_step = el / args.steps
-out["roofline"] = {"bound": "mfma", "achieved": round(1.061952e6 * per_step / sec_step / 1e12, 3), "peak": 157.3, "unit": "TFLOP/s",
-                   "frac": round(1.061952e6 * per_step / sec_step / 157.3e12, 4), "traffic": None,
-                   "entries_per_step": {"reference": total_entries / F, "computed": round(per_step, 1)},
-                   "reference_formulation_equivalent_TFLOPs": round(179.4e9 / sec_step / 1e12, 1),
-                   "note": "executed flops of the computed entries; the six GEMMs around the attention have K = 136..444 (near the HBM ridge) and run at ~45 TFLOP/s"}
-if args.cpu_steps > 0:
-    import bench                                   # the CPU-baseline leg lives in bench.py (the only non-test user of oracle/)
-    hb = [[x.cpu().numpy()[j * B:(j + 1) * B] for x in batches[0]] for j in range(min(F, args.cpu_steps))]
-    out["cpu_baseline"] = bench.cpu_baseline_tgat(data, nf, ef, params, hb, K, len(hb), B)
-print(json.dumps(out))
+ap.add_argument("--steps", type=int, default=64); ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--edges", type=int, default=672447); ap.add_argument("--cpu-seconds", type=float, default=20.0)
+ap.add_argument("--fuse-steps", type=int, default=32)
+a = ap.parse_args()
+print(json.dumps(bench.bench_tgat("cuda:0", steps=a.steps, warmup=a.warmup, fuse_steps=a.fuse_steps, edges=a.edges, cpu_budget_s=a.cpu_seconds)))
