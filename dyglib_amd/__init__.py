@@ -11,8 +11,7 @@ from .synthetic import InteractionData  # noqa: F401
 __all__ = ["DyGFormer", "TGAT", "MemoryModel", "MergeLayer", "TimeEncoder", "NeighborSampler", "get_neighbor_sampler", "TemporalCSR",
            "count_nodes_appearances", "InteractionData", "Data", "get_link_prediction_data",
            "get_link_prediction_metrics", "get_node_classification_metrics", "link_prediction_metrics_device",
-           "NegativeEdgeSampler", "get_idx_data_loader", "evaluate_model_link_prediction", "evaluate_model_node_classification",
-           "MLPClassifier"]
+           "NegativeEdgeSampler", "get_idx_data_loader", "evaluate_model_link_prediction"]
 
 
 def __getattr__(name):
@@ -26,7 +25,7 @@ def __getattr__(name):
     if name == "TGAT":
         from .tgat import TGAT
         return TGAT
-    if name in ("MergeLayer", "TimeEncoder", "MLPClassifier"):
+    if name in ("MergeLayer", "TimeEncoder"):
         from . import modules
         return getattr(modules, name)
     if name in ("NeighborSampler", "get_neighbor_sampler", "count_nodes_appearances"):
@@ -38,7 +37,7 @@ def __getattr__(name):
     if name in ("get_link_prediction_metrics", "get_node_classification_metrics", "link_prediction_metrics_device"):
         from . import metrics
         return getattr(metrics, name)
-    if name in ("NegativeEdgeSampler", "get_idx_data_loader", "evaluate_model_link_prediction", "evaluate_model_node_classification"):
+    if name in ("NegativeEdgeSampler", "get_idx_data_loader", "evaluate_model_link_prediction"):
         from . import evaluate
         return getattr(evaluate, name)
     if name == "TemporalCSR":

@@ -19,15 +19,29 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
 LIB_NAME = "libdygnn_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ["csr_host.cpp", "sampler.hip", "cooccurrence.hip", "dygformer_generic.hip", "dygformer_fused.hip", "dygformer_fused3.hip", "dygformer_train.hip",
+SOURCES = ["csr_host.cpp", "sampler.hip", "cooccurrence.hip", "dygformer_generic.hip", "dygformer_fused3.hip", "dygformer_train.hip",
            "dygformer_api.hip", "tgat.hip", "metrics.hip"]
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-ffp-contract=off"]   # contractions are written explicitly (fmaf) where the oracle has them
 
 
-VARIANTS = {"": [], "stamps": ["-DDYGNN_STAMPS=1"], "nogelu": ["-DDYGNN_STAMPS=1", "-DDYGNN_ABLATE_GELU=1"], "noload": ["-DDYGNN_STAMPS=1", "-DDYGNN_ABLATE_NOLOAD=1"],
-            "tgatnocos": ["-DDYGNN_ABLATE_TGAT_COS=1"], "tgatnogather": ["-DDYGNN_ABLATE_TGAT_GATHER=1"]}
+# "stamps": diagnostic build with in-kernel s_memtime phase stamps (tools/phase_profile.py)
+# "asan":   HOST code (CSR builder, argument validation, packing / planning code of every entry point) under AddressSanitizer +
+#           UndefinedBehaviorSanitizer; hipcc leaves the gfx950 code objects unsanitized (GPU ASan needs xnack+, unavailable here).
+#           Driven by tests/test_sanitizers_cpu.py on the CPU box, never loaded by the product path.
+SANITIZE = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-shared-libsan", "-Wno-option-ignored"]
+VARIANTS = {"": [], "stamps": ["-DDYGNN_STAMPS=1"], "asan": SANITIZE}
+LINK_EXTRA = {"asan": ["-fsanitize=address,undefined", "-shared-libsan"]}
+
+
+def asan_runtime() -> str:
+    """clang's shared ASan runtime (to LD_PRELOAD into a process that dlopens the asan variant)."""
+    import glob
+    hits = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    if not hits:
+        raise RuntimeError("libclang_rt.asan-x86_64.so not found under /opt/rocm/lib/llvm")
+    return hits[0]
 
 
 def lib_path(variant: str = "") -> str:
@@ -75,7 +89,7 @@ def build(force: bool = False, verbose: bool = True, variant: str = "") -> str:
     os.makedirs(obj_dir, exist_ok=True)
     with cf.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
         objs: List[str] = list(ex.map(lambda s: _compile(s, obj_dir, VARIANTS[variant]), SOURCES))
-    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", out]
+    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *LINK_EXTRA.get(variant, []), *objs, "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

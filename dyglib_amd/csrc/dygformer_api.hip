@@ -8,14 +8,6 @@ int forward_generic(const Dims&, const PackedLayout&, const dygnn_dygformer_weig
                     const float* node_feat, const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times,
                     int64_t B, int64_t G, float* out_src, float* out_dst, char* ws, const WorkspaceLayout&, const dygnn_dygformer_taps*,
                     hipStream_t);
-// dygformer_fused.hip
-bool fused_supported(const Dims&);
-int pack_fused(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, float* packed, hipStream_t);
-int forward_fused(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, const float* packed, const dygnn_csr*,
-                  const float* node_feat, const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times,
-                  int64_t B, int64_t G, float* out_src, float* out_dst, char* ws, const WorkspaceLayout&, const dygnn_dygformer_taps*,
-                  hipStream_t);
-
 // dygformer_fused3.hip
 bool fused3_supported(const Dims&);
 int pack_fused3(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, float* packed, hipStream_t);
@@ -136,11 +128,10 @@ extern "C" size_t dygnn_dygformer_workspace_bytes(const dygnn_dygformer_config* 
 // impl as in dygnn_dygformer_forward.  The fused kernels keep every activation on chip: they only need the per-query search results
 // (a few bytes per pair); the generic path also needs its HBM activation buffers (~29 KB per token).
 extern "C" size_t dygnn_dygformer_workspace_bytes_for(const dygnn_dygformer_config* cfg, int64_t batch, int32_t impl) {
-    if (check_config(cfg) != DYGNN_OK || batch < 0 || impl < 0 || impl > 3) return 0;
+    if (check_config(cfg) != DYGNN_OK || batch < 0 || !(impl == 0 || impl == 1 || impl == 3)) return 0;
     const Dims d = make_dims(*cfg);
     const WorkspaceLayout wl = make_workspace_layout(d, batch);
-    const bool generic = impl == 1 || (impl == 0 && !fused3_supported(d) && !fused_supported(d)) || (impl == 2 && !fused_supported(d)) ||
-                         (impl == 3 && !fused3_supported(d));
+    const bool generic = impl == 1 || !fused3_supported(d);
     return generic ? wl.total : wl.X;
 }
 
@@ -156,8 +147,6 @@ extern "C" int dygnn_dygformer_pack(const dygnn_dygformer_config* cfg, const dyg
         return DYGNN_E_WORKSPACE;
     }
     if (int rc = pack_generic(d, pl, w, static_cast<float*>(packed), as_stream(stream))) return rc;
-    if (fused_supported(d))
-        if (int rc = pack_fused(d, pl, w, static_cast<float*>(packed), as_stream(stream))) return rc;
     if (fused3_supported(d))
         if (int rc = pack_fused3(d, pl, w, static_cast<float*>(packed), as_stream(stream))) return rc;
     return DYGNN_OK;
@@ -177,7 +166,7 @@ extern "C" int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg, const 
     if (group_size == 0 || group_size > batch) group_size = batch;      // one group = the reference's single call
     DYGNN_REQUIRE(packed && node_feat && edge_feat, "forward: null table / packed pointer");
     DYGNN_REQUIRE(batch == 0 || (src && dst && times && out_src && out_dst && workspace), "forward: null pointer");
-    DYGNN_REQUIRE(impl >= 0 && impl <= 3, "forward: impl must be 0 (auto), 1 (generic), 2 (fused, wave-pair layout) or 3 (fused, token-owner layout)");
+    DYGNN_REQUIRE(impl == 0 || impl == 1 || impl == 3, "forward: impl must be 0 (auto), 1 (generic) or 3 (fused, token-owner layout)");
     if (batch == 0) return DYGNN_OK;
     const WorkspaceLayout wl = make_workspace_layout(d, batch);
     const size_t need = dygnn_dygformer_workspace_bytes_for(cfg, batch, impl);
@@ -186,19 +175,13 @@ extern "C" int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg, const 
         return DYGNN_E_WORKSPACE;
     }
     const PackedLayout pl = make_packed_layout(d);
-    const bool can_fuse = fused_supported(d);
-    if (impl == 2 && !can_fuse) {
-        set_error("forward: fused kernel does not support this shape (D=%d H=%d tokens<=%d)", d.D, d.H, d.Tmax);
-        return DYGNN_E_UNSUPPORTED;
-    }
     const bool can_fuse3 = fused3_supported(d);
     if (impl == 3 && !can_fuse3) {
         set_error("forward: token-owner fused kernel does not support this shape (D=%d H=%d tokens<=%d)", d.D, d.H, d.Tmax);
         return DYGNN_E_UNSUPPORTED;
     }
     auto fn = forward_generic;
-    if (impl == 3 || (impl == 0 && can_fuse3)) fn = forward_fused3;          // auto: token-owner kernel first
-    else if (impl == 2 || (impl == 0 && can_fuse)) fn = forward_fused;
+    if (impl == 3 || (impl == 0 && can_fuse3)) fn = forward_fused3;
     return fn(d, pl, w, static_cast<const float*>(packed), csr, node_feat, edge_feat, src, dst, times, batch, group_size, out_src, out_dst,
               static_cast<char*>(workspace), wl, taps, as_stream(stream));
 }

@@ -6,7 +6,7 @@
 //   * LayerNorm is wave-local (register sums + two cross-lane adds) and its output IS the MFMA B operand of the
 //     QKV / FFN products — no LDS round trip, no partial-sum exchange between waves, no K-split;
 //   * Q^T, softmax(S)^T, O^T and gelu(H)^T feed the next product straight from accumulators (same layout trick
-//     as dygformer_fused.hip: an accumulator tile is the B operand of the product that sums over its rows).
+//     an accumulator tile is the B operand of the product that sums over its rows).
 // Only K and V of ONE head at a time live in LDS ([128 tokens][100], 2 x 51.2 KB); heads run back to back.
 //
 // Weights: all 8 waves consume the SAME fragments in the SAME order, so the whole model is ONE linear stream of
@@ -78,7 +78,11 @@ __device__ __forceinline__ float row_sum16(float v) {
     return v;
 }
 
-// cos for the time encoder and erf for GELU: same functions as dygformer_fused.hip (see the derivations there)
+// cos for the time encoder.  The argument w*dt+b reaches 2.7e6 rad where libm's cosf takes its slow Payne-Hanek path; here x/(2 pi) is
+// formed as a two-float product (INV_HI + INV_LO = 1/(2 pi) to 2^-52), its fractional part u in [0, 0.5] is folded to [0, 0.25] and
+// cos(2 pi u) evaluated by an even degree-12 minimax polynomial (|err| <= 6e-8 on the folded range); beyond 3e7 the product's rounding
+// error would exceed 1e-7 turns and libm is called instead (tests/test_dygformer_gpu.py::test_large_timestamps_take_the_libm_cosine_path).
+// erf for the exact GELU: Abramowitz & Stegun 7.1.26 (|err| <= 1.5e-7), branch-free.
 __device__ __forceinline__ float cos_time(float x) {
     if (!(fabsf(x) <= 3.0e7f)) return cosf(x);
     const float INV_HI = 0.15915493667125702f, INV_LO = 6.4206382432985265e-09f;
@@ -109,11 +113,7 @@ __device__ __forceinline__ float erf_as(float x) {
     const float e = __expf(-ax * ax);
     return copysignf(fmaf(-p * t, e, 1.0f), x);
 }
-#ifdef DYGNN_ABLATE_GELU      // timing experiment only (wrong results): what the FFN costs without its activation
-__device__ __forceinline__ float gelu_erf(float v) { return v; }
-#else
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f)); }
-#endif
 
 struct LayerP {
     const float* b1;      // [800]; every other per-layer vector travels in the weight stream
@@ -137,7 +137,7 @@ struct Args {
     float *out_src, *out_dst;
     float* tap_enc; float* tap_layer[DYGNN_MAX_LAYERS];
     unsigned long long* stamps;
-    int64_t B, G;
+    int64_t B, G, num_nodes;
     int Fn, Fe, Ft, P, L, NL, Tmax;
     int nchunk[4];
     float qscale;
@@ -343,7 +343,9 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                 float tn = 0.f;
                 id = 0;
                 if (j == 0) {
-                    id = (int32_t)(is_dst ? a.dst[b] : a.src[b]); tn = (float)tq;
+                    const int64_t qid = is_dst ? a.dst[b] : a.src[b];
+                    id = qid < 0 || qid >= a.num_nodes ? 0 : (int32_t)qid;      // a bad query id is the padding node, as in sampler.hip (never a fault)
+                    tn = (float)tq;
                 } else if (j <= m) {
                     const int64_t pos = a.end_pos[q] - m + (j - 1);
                     id = a.nbr[pos]; e = a.eid[pos]; tn = (float)a.ts[pos];
@@ -1089,17 +1091,14 @@ int forward_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_
     a.out_src = out_src; a.out_dst = out_dst;
     a.tap_enc = taps ? taps->encoder_input : nullptr;
     a.stamps = taps ? reinterpret_cast<unsigned long long*>(taps->phase_cycles) : nullptr;
-    a.B = B; a.G = G; a.Fn = d.Fn; a.Fe = d.Fe; a.Ft = d.Ft; a.P = d.P; a.L = d.L; a.NL = d.NL; a.Tmax = d.Tmax;
+    a.B = B; a.G = G; a.num_nodes = csr->num_nodes; a.Fn = d.Fn; a.Fe = d.Fe; a.Ft = d.Ft; a.P = d.P; a.L = d.L; a.NL = d.NL; a.Tmax = d.Tmax;
     const int K[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * d.C};
     for (int ch = 0; ch < 4; ++ch) a.nchunk[ch] = (K[ch] + 15) / 16;
     a.qscale = (float)sqrt(1.0 / (double)d.hd);
     if (taps && taps->seq_lens) DYGNN_HIP(hipMemcpyAsync(taps->seq_lens, ws + wl.dims + 2 * sizeof(int32_t), 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-    static bool attr_set = false;
-    if (!attr_set) {
-        DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        attr_set = true;
-    }
+    // per device and cheap: set on every call (a process may drive several GPUs, or call from several threads)
+    DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     if (f.np == 2) hipLaunchKernelGGL(k_dygformer_fused3<4>, dim3((unsigned)((B + 1) / 2)), dim3(512), kLdsBytes, s, a);
     else hipLaunchKernelGGL(k_dygformer_fused3<8>, dim3((unsigned)B), dim3(512), kLdsBytes, s, a);
     DYGNN_LAUNCH_CHECK();

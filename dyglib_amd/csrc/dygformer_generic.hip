@@ -1,5 +1,5 @@
 // DyGFormer forward, generic path (any F/C/P/L/H, T <= 128 tokens per pair): a correctness-first
-// multi-kernel pipeline with activations in HBM.  The fused MFMA kernel (dygformer_fused.hip)
+// multi-kernel pipeline with activations in HBM.  The fused MFMA kernel (dygformer_fused3.hip)
 // is the fast path for the headline shape; this path covers every other shape and is the
 // on-device cross-check for the fused one.  No host synchronisation anywhere: the batch-wide
 // padded lengths S_src/S_dst (models/DyGFormer.py:219-226) stay on the device in CallDims and
@@ -158,7 +158,9 @@ __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
         int32_t id = 0, e = 0;
         float tn = 0.f;
         if (j == 0) {
-            id = (int32_t)(is_dst ? a.dst[b] : a.src[b]); tn = (float)t;
+            const int64_t qid = is_dst ? a.dst[b] : a.src[b];
+            id = qid < 0 || qid >= a.g.num_nodes ? 0 : (int32_t)qid;      // a bad query id is the padding node (never a fault)
+            tn = (float)t;
         } else if (j <= m) {
             const int64_t pos = a.end_pos[q] - m + (j - 1);
             id = a.g.nbr[pos]; e = a.g.eid[pos]; tn = (float)a.g.ts[pos];

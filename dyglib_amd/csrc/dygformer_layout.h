@@ -46,12 +46,10 @@ struct PackedLayout {
     size_t f0T[DYGNN_MAX_LAYERS];     // [D][4D]
     size_t f1T[DYGNN_MAX_LAYERS];     // [4D][D]
     size_t outputT;                   // [D][Fn]
-    size_t fused;                     // start of the fused-kernel section (fragment-ordered weights)
     size_t fused3;                    // start of the token-owner fused kernel's section (one fragment stream)
     size_t total;                     // floats
 };
 
-size_t fused_packed_floats(const Dims& d);    // defined in dygformer_fused.hip
 size_t fused3_packed_floats(const Dims& d);   // defined in dygformer_fused3.hip
 
 inline PackedLayout make_packed_layout(const Dims& d) {
@@ -68,8 +66,6 @@ inline PackedLayout make_packed_layout(const Dims& d) {
         p.f1T[l] = take((size_t)4 * d.D * d.D);
     }
     p.outputT = take((size_t)d.D * d.Fn);
-    p.fused = o;
-    o += (fused_packed_floats(d) + 63) & ~size_t(63);
     p.fused3 = o;
     o += (fused3_packed_floats(d) + 63) & ~size_t(63);
     p.total = o;

@@ -648,6 +648,7 @@ struct EmbedArgs {
     int64_t B; int Ss, Sd, Ts, T, P, L, Fn, Fe, Ft, C;
     int32_t *ids, *c0, *c1; float* dts;          // meta [B][S]
     float *Pn, *Pe, *Pt, *Pc;                    // patch matrices [B*T][P*F]
+    int64_t num_nodes;                           // rows of the CSR: query ids outside [0, num_nodes) are the padding node
 };
 __global__ __launch_bounds__(256) void k_embed_inputs(const EmbedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(256) void k_embed_inputs(const EmbedArgs a) {
         const int32_t m = len < a.L - 1 ? len : a.L - 1;
         int32_t id = 0, e = 0;
         float tn = 0.f;
-        if (j == 0) { id = (int32_t)(is_dst ? a.dst[b] : a.src[b]); tn = (float)t; }
+        if (j == 0) { const int64_t qid = is_dst ? a.dst[b] : a.src[b]; id = qid < 0 || qid >= a.num_nodes ? 0 : (int32_t)qid; tn = (float)t; }
         else if (j <= m) { const int64_t pos = a.end_pos[q] - m + (j - 1); id = a.nbr[pos]; e = a.eid[pos]; tn = (float)a.ts[pos]; }
         ids[p] = id; eids[p] = e; dts[p] = (float)(t - (double)tn);
     }
@@ -930,7 +931,7 @@ extern "C" int dygnn_dygformer_train_forward(const dygnn_dygformer_config* cfg, 
     DYGNN_LAUNCH_CHECK();
     EmbedArgs ea{csr->indptr, csr->nbr, csr->eid, csr->ts, src, dst, times, reinterpret_cast<const int32_t*>(ws + p.wl.hist_len),
                  reinterpret_cast<const int64_t*>(ws + p.wl.end_pos), node_feat, edge_feat, w->time_w, w->time_b, F32(p.lut), B, Ss, Sd, Ts, T, d.P, d.L,
-                 d.Fn, d.Fe, d.Ft, C, I32(p.ids), I32(p.c0), I32(p.c1), F32(p.dts), F32(p.Pn), F32(p.Pe), F32(p.Pt), F32(p.Pc)};
+                 d.Fn, d.Fe, d.Ft, C, I32(p.ids), I32(p.c0), I32(p.c1), F32(p.dts), F32(p.Pn), F32(p.Pe), F32(p.Pt), F32(p.Pc), csr->num_nodes};
     hipLaunchKernelGGL(k_embed_inputs, dim3((unsigned)B, (unsigned)(T >= 8 ? 8 : 1)), dim3(256), (size_t)5 * S * 4, s, ea);
     DYGNN_LAUNCH_CHECK();
     // projections (DyGFormer.py:148-157): X0[:, 50ch : 50ch+50] = P_ch . W_ch^T + b_ch

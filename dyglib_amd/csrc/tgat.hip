@@ -239,12 +239,8 @@ __global__ __launch_bounds__(256) void k_tgat_attn_lin(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < KCACHE; ++j) {
             const int64_t r = i * k + (j < k ? j : 0);
-#if defined(DYGNN_ABLATE_TGAT_GATHER)      // diagnostic build only: every gather hits row 0
-            const int64_t nrow = 0, erow = 0;
-#else
             const int64_t nrow = h_lower ? n + r : (int64_t)lower_ids[n + r];
             const int64_t erow = nbr_eid[r];
-#endif
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) xs[j][ps] = *reinterpret_cast<const f4*>(bp[ps] + (cls[ps] == 0 ? nrow : erow) * st[ps]);
         }
@@ -259,10 +255,6 @@ __global__ __launch_bounds__(256) void k_tgat_attn_lin(const float* __restrict__
 #pragma unroll 1
                 for (int j = 0; j < k; ++j) {
                     const float dt = nbr_dt[i * k + j];
-#if defined(DYGNN_ABLATE_TGAT_COS)         // diagnostic build only
-                    *reinterpret_cast<f4*>(tf + j * Ft + f) = f4{dt, w.x, b.y, w.z};
-                    continue;
-#endif
                     *reinterpret_cast<f4*>(tf + j * Ft + f) = f4{cos_time_t(fmaf(dt, w.x, b.x)), cos_time_t(fmaf(dt, w.y, b.y)), cos_time_t(fmaf(dt, w.z, b.z)),
                                                                 cos_time_t(fmaf(dt, w.w, b.w))};
                 }
@@ -761,9 +753,11 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
 // persist the update for the batch nodes that have a pending message and clear it (MemoryModel.py:142-145, :425-459).  A node that
 // occurs several times is handled by several workgroups: each either still sees the flag and writes the same values, or sees it cleared
 __global__ void k_tgn_persist_clear(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t B, const float* __restrict__ Mnew,
-                                    const double* __restrict__ msg_t, int Fn, float* __restrict__ M, float* __restrict__ U, int32_t* __restrict__ has_msg) {
+                                    const double* __restrict__ msg_t, int Fn, float* __restrict__ M, float* __restrict__ U, int32_t* __restrict__ has_msg,
+                                    int64_t N) {
     const int64_t r = blockIdx.x;                  // 0..2B-1
     const int64_t node = r < B ? src[r] : dst[r - B];
+    if (node < 0 || node >= N) return;             // ids outside the state tables are never written (the host API raises IndexError for them)
     const bool pending = has_msg[node] != 0;       // the same for every thread of the workgroup unless a twin clears it meanwhile: harmless
     if (pending) {
         for (int f = threadIdx.x; f < Fn; f += blockDim.x) M[node * Fn + f] = Mnew[node * Fn + f];
@@ -774,22 +768,25 @@ __global__ void k_tgn_persist_clear(const int64_t* __restrict__ src, const int64
 }
 // Messages are stored source role first, then destination role (MemoryModel.py:147-161), and only a node's LAST stored message is ever
 // read (:284-291): entry e = role * B + i (role 0 = source), the winner of a node is its largest e
-__global__ void k_tgn_winner(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t B, int32_t* __restrict__ win) {
+__global__ void k_tgn_winner(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t B, int32_t* __restrict__ win, int64_t N) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < 2 * B) atomicMax(&win[e < B ? src[e] : dst[e - B]], (int32_t)e);
+    if (e >= 2 * B) return;
+    const int64_t node = e < B ? src[e] : dst[e - B];
+    if (node >= 0 && node < N) atomicMax(&win[node], (int32_t)e);
 }
 // new raw message of the role-node of entry e: [M[who] | M[other] | cos(w (t - U[who]) + b) | edge feature]  (MemoryModel.py:223-241)
 __global__ __launch_bounds__(256) void k_tgn_message(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const double* __restrict__ times,
                                                        const int64_t* __restrict__ eids, int64_t B, const float* __restrict__ M, const float* __restrict__ U,
                                                        const float* __restrict__ edge_feat, const float* __restrict__ tw, const float* __restrict__ tb,
                                                        int Fn, int Fe, int Ft, const int32_t* __restrict__ win, float* __restrict__ msg,
-                                                       double* __restrict__ msg_t, int32_t* __restrict__ has_msg) {
+                                                       double* __restrict__ msg_t, int32_t* __restrict__ has_msg, int64_t N) {
     const int64_t e = blockIdx.x;
     const bool role = e >= B;
     const int64_t i = role ? e - B : e;
     const int64_t node = role ? dst[i] : src[i];
-    if (win[node] != (int32_t)e) return;           // only the last stored message is observable
     const int64_t o = role ? src[i] : dst[i];
+    if (node < 0 || node >= N || o < 0 || o >= N) return;      // never index the state tables out of range
+    if (win[node] != (int32_t)e) return;           // only the last stored message is observable
     const int D = 2 * Fn + Ft + Fe;
     const float dt = (float)times[i] - U[node];    // float32 - float32 (MemoryModel.py:232-233)
     float* m = msg + node * D;
@@ -973,15 +970,15 @@ static int tgn_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weigh
     if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, wt, wt_bytes, stream, nullptr, true)) return rc;
     if (!edges_are_positive) return DYGNN_OK;
     // 3. persist + clear for the batch nodes (MemoryModel.py:142-145)
-    hipLaunchKernelGGL(k_tgn_persist_clear, dim3((unsigned)(2 * n_pos)), dim3(64), 0, s, src, dst, n_pos, Mnew, st->msg_time, Fn, st->memory, st->last_update, st->has_msg);
+    hipLaunchKernelGGL(k_tgn_persist_clear, dim3((unsigned)(2 * n_pos)), dim3(64), 0, s, src, dst, n_pos, Mnew, st->msg_time, Fn, st->memory, st->last_update, st->has_msg, N);
     DYGNN_LAUNCH_CHECK();
     // 4. new raw messages of both roles (one winner pass, one message pass)
     hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, win, N, -1);
     DYGNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_tgn_winner, dim3((unsigned)ceil_div(2 * n_pos, 256)), dim3(256), 0, s, src, dst, n_pos, win);
+    hipLaunchKernelGGL(k_tgn_winner, dim3((unsigned)ceil_div(2 * n_pos, 256)), dim3(256), 0, s, src, dst, n_pos, win, N);
     DYGNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_tgn_message, dim3((unsigned)(2 * n_pos)), dim3(256), 0, s, src, dst, times, edge_ids, n_pos, st->memory, st->last_update, edge_feat,
-                       w->time_w, w->time_b, Fn, Fe, Ft, win, st->msg, st->msg_time, st->has_msg);
+                       w->time_w, w->time_b, Fn, Fe, Ft, win, st->msg, st->msg_time, st->has_msg, N);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }

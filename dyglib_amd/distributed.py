@@ -10,8 +10,12 @@ exchange is the reduction of the per-batch metric sums — 3 float64 scalars per
 nowhere near the per-link xGMI bandwidth.
 
 The reference computes per-batch AP / AUC with scikit-learn on the host (utils/metrics.py:5-19, one
-device->host sync per batch).  `binary_auc` / `average_precision` below are the same estimators on the
-device (tie handling identical to sklearn's), so a step needs no host round trip.
+device->host sync per batch); here they come from the device kernel behind
+`dyglib_amd.metrics.link_prediction_metrics_device` (metrics.hip), so a step needs no host round trip.
+
+Data-parallel training gives every rank the SAME number of optimizer steps (`shard_steps`): a rank whose
+share of the batches is one short takes part in the last gradient all-reduce with zeros, so no collective
+is ever issued by only some of the ranks.
 """
 from __future__ import annotations
 
@@ -35,33 +39,13 @@ def owner_of_batch(batch_index: int, world_size: int) -> int:
     return batch_index % world_size
 
 
-# ---------------------------------------------------------------------------------------------------
-# metrics on the device (utils/metrics.py:5-19 with labels = [1]*len(pos) + [0]*len(neg))
-# ---------------------------------------------------------------------------------------------------
-def binary_auc(pos: torch.Tensor, neg: torch.Tensor) -> torch.Tensor:
-    """roc_auc_score for scores cat(pos,neg): P(pos > neg) + 0.5 P(pos == neg) (the Mann-Whitney statistic,
-    which is what sklearn's trapezoidal ROC integral equals, ties included)."""
-    p, n = pos.double().reshape(-1, 1), neg.double().reshape(1, -1)
-    return ((p > n).double().mean() + 0.5 * (p == n).double().mean())
-
-
-def average_precision(pos: torch.Tensor, neg: torch.Tensor) -> torch.Tensor:
-    """average_precision_score: sum_k (R_k - R_{k-1}) P_k over the DISTINCT score thresholds in
-    descending order (sklearn groups tied scores into one threshold)."""
-    scores = torch.cat([pos.reshape(-1), neg.reshape(-1)]).double()
-    labels = torch.cat([torch.ones(pos.numel(), dtype=torch.float64, device=scores.device),
-                        torch.zeros(neg.numel(), dtype=torch.float64, device=scores.device)])
-    order = torch.argsort(scores, descending=True, stable=True)
-    s, y = scores[order], labels[order]
-    tp = torch.cumsum(y, 0)
-    k = torch.arange(1, s.numel() + 1, dtype=torch.float64, device=s.device)
-    last_of_group = torch.ones_like(s, dtype=torch.bool)
-    last_of_group[:-1] = s[1:] != s[:-1]
-    tp_g, k_g = tp[last_of_group], k[last_of_group]
-    precision = tp_g / k_g
-    recall = tp_g / max(pos.numel(), 1)
-    prev = torch.cat([torch.zeros(1, dtype=torch.float64, device=s.device), recall[:-1]])
-    return ((recall - prev) * precision).sum()
+def shard_steps(num_batches: int, rank: int, world_size: int) -> list:
+    """Training schedule of this rank: ceil(num_batches / world) steps on EVERY rank — the batch index of each step, or None
+    where the round-robin deal leaves this rank without a batch (it then joins that step's gradient all-reduce with zeros).
+    Every rank issuing the same number of collectives is what keeps an uneven split from hanging the job."""
+    mine = list(shard_batch_indices(num_batches, rank, world_size))
+    n_steps = (num_batches + world_size - 1) // world_size
+    return mine + [None] * (n_steps - len(mine))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -75,17 +59,31 @@ def reduce_metric_sums(local_sums: torch.Tensor, group=None) -> torch.Tensor:
     return local_sums
 
 
+def _device_metrics(predicts: torch.Tensor, labels: torch.Tensor):
+    """AP and ROC AUC of one batch on the device (metrics.hip through the C ABI): the product path."""
+    from .metrics import link_prediction_metrics_device
+    ap, auc, _, status = link_prediction_metrics_device(predicts.reshape(1, -1).float(), labels.reshape(1, -1).float())
+    return ap[0], auc[0]
+
+
 def evaluate_sharded(step_fn: Callable[[int], Tuple[torch.Tensor, torch.Tensor]], num_batches: int,
-                     rank: int = 0, world_size: int = 1, device: Optional[torch.device] = None, group=None) -> dict:
+                     rank: int = 0, world_size: int = 1, device: Optional[torch.device] = None, group=None,
+                     metrics_fn: Optional[Callable] = None) -> dict:
     """The evaluation loop of evaluate_models_utils.py:49-152, sharded: `step_fn(batch_index)` returns the
     positive and negative probabilities of one batch (evaluate_models_utils.py:140-141); each rank runs its
     own batches, accumulates [sum AP, sum AUC, count] on its device and ONE all-reduce at the end gives every
-    rank the global means (the reference averages the per-batch metrics, train_link_prediction.py:301-306)."""
+    rank the global means (the reference averages the per-batch metrics, train_link_prediction.py:301-306).
+    `metrics_fn(predicts, labels) -> (ap, auc)` defaults to the device kernel (dygnn_link_metrics); the CPU
+    tests of this loop pass their own checker."""
+    metrics_fn = metrics_fn or _device_metrics
     sums = None
     for i in shard_batch_indices(num_batches, rank, world_size):
         pos, neg = step_fn(i)
-        m = torch.stack([average_precision(pos, neg), binary_auc(pos, neg),
-                         torch.ones((), dtype=torch.float64, device=pos.device)])
+        predicts = torch.cat([pos.reshape(-1), neg.reshape(-1)])                                   # evaluate_models_utils.py:142-143
+        labels = torch.cat([torch.ones_like(pos.reshape(-1)), torch.zeros_like(neg.reshape(-1))])
+        ap, auc = metrics_fn(predicts, labels)
+        m = torch.stack([torch.as_tensor(ap, dtype=torch.float64, device=predicts.device), torch.as_tensor(auc, dtype=torch.float64, device=predicts.device),
+                         torch.ones((), dtype=torch.float64, device=predicts.device)])
         sums = m if sums is None else sums + m
     if sums is None:       # a rank without batches still takes part in the collective
         sums = torch.zeros(3, dtype=torch.float64, device=device or "cpu")
@@ -102,6 +100,25 @@ def evaluate_sharded(step_fn: Callable[[int], Tuple[torch.Tensor, torch.Tensor]]
 # 4 MB ring all-reduce costs ~50 us + latency; splitting it into per-tensor collectives would only add latency).
 # The effective batch becomes world * 200, as with torch DDP.
 # ---------------------------------------------------------------------------------------------------
+def train_sharded(step_fn: Callable[[int], torch.Tensor], parameters, optimizer, num_batches: int, rank: int = 0, world_size: int = 1,
+                  group=None) -> list:
+    """One data-parallel epoch (train_link_prediction.py:188-257, sharded): `step_fn(batch_index)` runs forward + loss for one batch of this
+    rank and returns the loss; every rank performs ceil(num_batches / world) optimizer steps (`shard_steps`) — zero_grad, backward where it
+    has a batch, ONE gradient all-reduce, optimizer.step — so the ranks stay in lock-step when num_batches % world != 0.  Gradients are
+    averaged over the world (as torch DDP does).  Returns the losses of this rank's own batches."""
+    params = [p for p in parameters]
+    losses = []
+    for i in shard_steps(num_batches, rank, world_size):
+        optimizer.zero_grad()
+        if i is not None:
+            loss = step_fn(i)
+            loss.backward()
+            losses.append(float(loss.detach()))
+        allreduce_gradients(params, group)          # an idle rank contributes zeros
+        optimizer.step()
+    return losses
+
+
 def allreduce_gradients(parameters: Iterable[torch.nn.Parameter], group=None) -> int:
     """Average the .grad of `parameters` over the ranks in one flattened bucket (parameters without a gradient take part
     with zeros, so every rank issues the same collective).  Returns the bucket's element count.  No-op for one rank."""

@@ -77,7 +77,7 @@ class _TrainFunction(torch.autograd.Function):
                                                C.cast(seq, C.c_void_p), _capi.current_stream_ptr())
         _capi.check(rc)
         ctx.model, ctx.ws, ctx.seq, ctx.B, ctx.dropout_p, ctx.seed = model, ws, seq, B, float(dropout_p), int(seed)
-        ctx.param_shapes = [p.shape for p in params]
+        ctx.param_versions = [(p.data_ptr(), p._version) for p in model.parameters()]
         return out_src, out_dst
 
     @staticmethod
@@ -87,6 +87,11 @@ class _TrainFunction(torch.autograd.Function):
         g_src = (g_src if g_src is not None else torch.zeros((ctx.B, model.node_feat_dim), device=dev)).contiguous().float()
         g_dst = (g_dst if g_dst is not None else torch.zeros((ctx.B, model.node_feat_dim), device=dev)).contiguous().float()
         params = list(model.parameters())
+        # the backward pass re-reads the CURRENT parameter values: they must be the ones the forward used (PyTorch raises the same
+        # way when a tensor saved for backward was modified in place, e.g. by an optimizer step between forward and backward)
+        if [(p.data_ptr(), p._version) for p in params] != ctx.param_versions:
+            raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: "
+                               "a DyGFormer parameter changed between this call's forward and its backward")
         flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)       # one fill for all gradient buffers
         grads, o = [], 0
         for p in params:
@@ -146,7 +151,7 @@ class DyGFormer(nn.Module):
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
         self._workspace: Dict[tuple, torch.Tensor] = {}
-        self.impl = 0                      # 0 auto, 1 generic, 2 fused (see include/dygnn.h)
+        self.impl = 0                      # 0 auto, 1 generic, 3 fused (see include/dygnn.h)
 
     # ---- reference API -------------------------------------------------------------------------
     def set_neighbor_sampler(self, neighbor_sampler: NeighborSampler):
@@ -162,6 +167,7 @@ class DyGFormer(nn.Module):
         """models/DyGFormer.py:68-194.  ndarray (or already-resident device tensor) [B] int64, [B] int64,
         [B] float64 -> two float32 tensors [B, node_feat_dim] on the model's device."""
         dev = self._device()
+        self._validate_ids(src_node_ids, dst_node_ids)
         src = self._to_dev(src_node_ids, torch.int64, dev)
         dst = self._to_dev(dst_node_ids, torch.int64, dev)
         tms = self._to_dev(node_interact_times, torch.float64, dev)
@@ -200,6 +206,7 @@ class DyGFormer(nn.Module):
         padded lengths), but the N*B pairs form one grid, which keeps all 256 CUs busy instead of B of them.
         Returns two float32 tensors [N, B, node_feat_dim]."""
         dev = self._device()
+        self._validate_ids(src_node_ids, dst_node_ids)
         src = self._to_dev(src_node_ids, torch.int64, dev)
         dst = self._to_dev(dst_node_ids, torch.int64, dev)
         tms = self._to_dev(node_interact_times, torch.float64, dev)
@@ -288,6 +295,34 @@ class DyGFormer(nn.Module):
         return tuple(s_ + (P - s_ % P) % P for s_ in S)
 
     # ---- plumbing ------------------------------------------------------------------------------
+    def _validate_ids(self, *id_arrays) -> None:
+        """The reference trusts ids and fails with IndexError (list / tensor indexing); here host inputs are range-checked per call
+        (two min/max over B ids) and the graph against the feature tables once per sampler, so no kernel can index outside a table."""
+        csr = self.neighbor_sampler.csr
+        if getattr(self, "_validated_csr", None) is not csr:
+            csr.check_tables(self.node_raw_features.shape[0], self.edge_raw_features.shape[0])
+            self._validated_csr = csr
+        for ids in id_arrays:
+            csr.check_query_ids(ids, limit=self.node_raw_features.shape[0])
+
+    def invalidate_packed(self) -> None:
+        """Drop the kernel-ready weight copy.  It is re-packed automatically when a parameter's version counter or address changes
+        (optimizer steps, load_state_dict, .to()), on every train()/eval() switch and by this call; writes through `p.data` do not
+        bump the version counter, so code that edits weights that way (custom init, EMA) calls this afterwards."""
+        self._packed_key = None
+
+    def train(self, mode: bool = True):
+        self._packed_key = None
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._packed_key = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._packed_key = None
+        return super().load_state_dict(*args, **kwargs)
+
     def _device(self) -> torch.device:
         dev = self.output_layer.weight.device
         if dev.type != "cuda":

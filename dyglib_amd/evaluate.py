@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .metrics import get_node_classification_metrics, link_prediction_metrics_device
+from .metrics import link_prediction_metrics_device
 
 
 class NegativeEdgeSampler(object):
@@ -139,57 +139,3 @@ def evaluate_model_link_prediction(model_name: str, model: nn.Module, neighbor_s
     if status.any():
         raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
     return [float(v) for v in loss], [{"average_precision": float(a), "roc_auc": float(u)} for a, u in zip(ap, auc)]
-
-
-def evaluate_model_node_classification(model_name: str, model: nn.Module, neighbor_sampler, evaluate_idx_data_loader, evaluate_data,
-                                       loss_func: nn.Module, num_neighbors: int = 20, time_gap: int = 2000, fuse_batches: int = 32):
-    """evaluate_models_utils.py:160-249 for the models of this package: `model` is nn.Sequential(backbone, MLPClassifier); the source
-    embedding of every interaction is classified, the loss is averaged over the batches and ROC AUC is taken over the whole split.
-    Returns (evaluate_total_loss, {'roc_auc': ...}) like the reference; batches are grouped per launch (DyGFormer, TGAT `recent`), the
-    predictions stay on the GPU and the host synchronises once."""
-    if model_name not in ("DyGFormer", "TGAT", "TGN"):
-        raise ValueError(f"Wrong value for model_name {model_name}!")
-    model[0].set_neighbor_sampler(neighbor_sampler)
-    model.eval()
-    backbone, head = model[0], model[1]
-    losses, y_trues, y_predicts = [], [], []
-
-    def flush(groups):
-        if not groups:
-            return
-        if model_name == "DyGFormer":
-            emb, _ = backbone.compute_src_dst_node_temporal_embeddings_many(np.stack([g[0] for g in groups]), np.stack([g[1] for g in groups]),
-                                                                            np.stack([g[2] for g in groups]))
-            embs = list(emb)
-        elif model_name == "TGAT" and neighbor_sampler.sample_neighbor_strategy == "recent":
-            cat = lambda c: np.concatenate([g[c] for g in groups])
-            emb, _ = backbone.compute_src_dst_node_temporal_embeddings(cat(0), cat(1), cat(2), num_neighbors=num_neighbors)
-            embs = list(emb.reshape(len(groups), len(groups[0][0]), -1))
-        elif model_name == "TGAT":
-            embs = [backbone.compute_src_dst_node_temporal_embeddings(g[0], g[1], g[2], num_neighbors=num_neighbors)[0] for g in groups]
-        else:       # TGN: positive calls, strictly in sequence (:196-203)
-            embs = [backbone.compute_src_dst_node_temporal_embeddings(g[0], g[1], g[2], edge_ids=g[3], edges_are_positive=True,
-                                                                      num_neighbors=num_neighbors)[0] for g in groups]
-        for g, e in zip(groups, embs):
-            predicts = head(x=e).squeeze(dim=-1).sigmoid()                                        # :229
-            labels = torch.from_numpy(np.ascontiguousarray(g[4])).float().to(predicts.device)      # :230
-            losses.append(loss_func(input=predicts, target=labels).double())
-            y_trues.append(labels)
-            y_predicts.append(predicts)
-
-    with torch.no_grad():
-        pending = []
-        for evaluate_data_indices in evaluate_idx_data_loader:
-            idx = evaluate_data_indices.numpy() if isinstance(evaluate_data_indices, torch.Tensor) else np.asarray(evaluate_data_indices)
-            g = (evaluate_data.src_node_ids[idx], evaluate_data.dst_node_ids[idx], evaluate_data.node_interact_times[idx],
-                 evaluate_data.edge_ids[idx], evaluate_data.labels[idx])
-            if pending and (len(pending[0][0]) != len(g[0]) or len(pending) >= max(1, fuse_batches)):
-                flush(pending)
-                pending = []
-            pending.append(g)
-        flush(pending)
-        if not losses:
-            raise ValueError("empty evaluation loader")
-        evaluate_metrics = get_node_classification_metrics(predicts=torch.cat(y_predicts, dim=0), labels=torch.cat(y_trues, dim=0))   # :244-247
-        evaluate_total_loss = float(torch.stack(losses).sum().item()) / len(losses)               # :242
-    return evaluate_total_loss, evaluate_metrics

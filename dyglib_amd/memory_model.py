@@ -137,8 +137,10 @@ class MemoryModel(nn.Module):
                                                  edges_are_positive: bool = True, num_neighbors: int = 20, _n_positive: int = None
                                                  ) -> Tuple[torch.Tensor, torch.Tensor]:
         """MemoryModel.py:87-168 (TGN).  Positive calls mutate the memory bank: issue batches in chronological order."""
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training-mode forward / backward through the HIP path is not built yet (SURVEY.md §8f-1)")
+        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
+            # eval mode with autograd recording would return tensors without a graph: loss.backward() would silently do nothing
+            raise NotImplementedError("MemoryModel forward with autograd recording (training) is not built on the HIP path (SURVEY.md §8f-1): "
+                                      "call it under torch.no_grad()")
         sampler = self.embedding_module.neighbor_sampler
         sampler._require_recent()
         dev = self.memory_bank.node_memories.device
@@ -149,6 +151,16 @@ class MemoryModel(nn.Module):
         self.memory_bank._alloc()
         to_dev = lambda x, dt: (x.to(device=dev, dtype=dt).contiguous() if isinstance(x, torch.Tensor)
                                 else torch.from_numpy(np.ascontiguousarray(x, dtype={torch.int64: np.int64, torch.float64: np.float64}[dt])).to(dev))
+        csr = sampler.csr
+        if getattr(self, "_validated_csr", None) is not csr:          # once per sampler: graph ids inside the tables and the memory bank
+            csr.check_tables(min(self.node_raw_features.shape[0], self.num_nodes), self.edge_raw_features.shape[0])
+            self._validated_csr = csr
+        csr.check_query_ids(src_node_ids, limit=self.num_nodes)        # IndexError like the reference's memory_bank indexing (MemoryModel.py:336)
+        csr.check_query_ids(dst_node_ids, limit=self.num_nodes)
+        if edge_ids is not None and not isinstance(edge_ids, torch.Tensor) and len(edge_ids):
+            e = np.asarray(edge_ids)
+            if int(e.min()) < 0 or int(e.max()) >= self.edge_raw_features.shape[0]:
+                raise IndexError(f"edge id out of bounds for edge_raw_features with {self.edge_raw_features.shape[0]} rows")
         src, dst, tms = to_dev(src_node_ids, torch.int64), to_dev(dst_node_ids, torch.int64), to_dev(node_interact_times, torch.float64)
         B = src.numel()
         assert dst.numel() == B and tms.numel() == B

@@ -55,21 +55,3 @@ class MergeLayer(nn.Module):
                                                   self.fc2.weight.data_ptr(), self.fc2.bias.data_ptr(), out.data_ptr(),
                                                   _capi.current_stream_ptr()))
         return out
-
-
-class MLPClassifier(nn.Module):
-    """Node-classification head fc3(drop(relu(fc2(drop(relu(fc1(x))))))) (models/modules.py:71-96): the caller's module around the hot
-    path (train_node_classification.py:204); parameters and forward are plain PyTorch-ROCm ops, names and shapes are the reference's."""
-
-    def __init__(self, input_dim: int, dropout: float = 0.1):
-        super().__init__()
-        self.fc1 = nn.Linear(input_dim, 80)
-        self.fc2 = nn.Linear(80, 10)
-        self.fc3 = nn.Linear(10, 1)
-        self.act = nn.ReLU()
-        self.dropout = nn.Dropout(dropout)
-
-    def forward(self, x: torch.Tensor):
-        x = self.dropout(self.act(self.fc1(x)))
-        x = self.dropout(self.act(self.fc2(x)))
-        return self.fc3(x)

@@ -61,6 +61,7 @@ class NeighborSampler:
 
     # ---- helpers -------------------------------------------------------------------------------
     def _queries_to_device(self, node_ids, node_interact_times) -> Tuple[torch.Tensor, torch.Tensor]:
+        self.csr.check_query_ids(node_ids)              # IndexError like the reference's list index (utils/utils.py:139)
         nodes = torch.as_tensor(np.ascontiguousarray(node_ids, dtype=np.int64)).to(self.device, non_blocking=True)
         # float32 query times (TGAT second hop, models/TGAT.py:107-110) widen exactly to float64
         times = torch.as_tensor(np.ascontiguousarray(node_interact_times, dtype=np.float64)).to(self.device, non_blocking=True)

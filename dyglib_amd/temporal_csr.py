@@ -26,6 +26,39 @@ class TemporalCSR:
         self.num_nodes = len(self.indptr) - 1
         self.num_entries = len(self.nbr)
         self._dev = {}          # device -> (tensors, ctypes struct)
+        self._max_ids = None    # (largest neighbour id, largest edge id), computed on first use
+
+    # ---- validation (the reference trusts ids: numpy / list indexing raises IndexError there) -----------------
+    def max_ids(self):
+        if self._max_ids is None:
+            self._max_ids = (int(self.nbr.max()) if self.num_entries else 0, int(self.eid.max()) if self.num_entries else 0)
+        return self._max_ids
+
+    def check_tables(self, num_node_rows: int, num_edge_rows: int) -> None:
+        """Every id the kernels can read through this graph indexes inside the feature tables: the rows of the query ids
+        (< num_nodes, see check_query_ids), of the CSR neighbours and of the CSR edge ids.  Called once per (sampler, model)."""
+        max_nbr, max_eid = self.max_ids()
+        if self.num_entries and (int(self.nbr.min()) < 0 or int(self.eid.min()) < 0):
+            raise IndexError("negative node / edge id in the adjacency")
+        if max_nbr >= num_node_rows:
+            raise IndexError(f"index {max_nbr} is out of bounds for node_raw_features with {num_node_rows} rows")
+        if max_eid >= num_edge_rows:
+            raise IndexError(f"index {max_eid} is out of bounds for edge_raw_features with {num_edge_rows} rows")
+
+    def check_query_ids(self, ids, limit: Optional[int] = None, what: str = "node id") -> None:
+        """IndexError for host (numpy / list) query ids outside [0, min(num_nodes, limit)) — the reference's behaviour
+        (utils/utils.py:139 list index, models/DyGFormer.py:259 tensor index).  Device tensors are not inspected (that would be a
+        synchronisation): the kernels treat such an id as the padding node."""
+        if isinstance(ids, torch.Tensor):
+            return
+        a = np.asarray(ids)
+        if a.size == 0:
+            return
+        hi = self.num_nodes if limit is None else min(self.num_nodes, int(limit))
+        lo_v, hi_v = int(a.min()), int(a.max())
+        if lo_v < 0 or hi_v >= hi:
+            bad = lo_v if lo_v < 0 else hi_v
+            raise IndexError(f"{what} {bad} is out of bounds for a graph / feature table with {hi} rows")
 
     # ---- construction -----------------------------------------------------------------------
     @classmethod

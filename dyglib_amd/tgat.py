@@ -67,8 +67,10 @@ class TGAT(nn.Module):
     def compute_src_dst_node_temporal_embeddings(self, src_node_ids, dst_node_ids, node_interact_times,
                                                  num_neighbors: int = 20) -> Tuple[torch.Tensor, torch.Tensor]:
         """models/TGAT.py:48-64: two float32 tensors [B, node_feat_dim] on the model's device."""
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training-mode forward / backward through the HIP path is not built yet (SURVEY.md §8f-1)")
+        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
+            # eval mode with autograd recording would return tensors without a graph: loss.backward() would silently do nothing
+            raise NotImplementedError("TGAT forward with autograd recording (training) is not built on the HIP path (SURVEY.md §8f-1): "
+                                      "call it under torch.no_grad()")
         random_strategy = self.neighbor_sampler.sample_neighbor_strategy != "recent"
         self.neighbor_sampler._check_strategy()
         dev = self.merge_layers[0].fc1.weight.device
@@ -79,6 +81,12 @@ class TGAT(nn.Module):
             self.edge_raw_features = self.edge_raw_features.to(dev)
         to_dev = lambda x, dt: (x.to(device=dev, dtype=dt).contiguous() if isinstance(x, torch.Tensor)
                                 else torch.from_numpy(np.ascontiguousarray(x, dtype={torch.int64: np.int64, torch.float64: np.float64}[dt])).to(dev))
+        csr = self.neighbor_sampler.csr
+        if getattr(self, "_validated_csr", None) is not csr:          # once per sampler: every id reachable through the graph is inside the tables
+            csr.check_tables(self.node_raw_features.shape[0], self.edge_raw_features.shape[0])
+            self._validated_csr = csr
+        csr.check_query_ids(src_node_ids, limit=self.node_raw_features.shape[0])       # IndexError like the reference (models/TGAT.py:85)
+        csr.check_query_ids(dst_node_ids, limit=self.node_raw_features.shape[0])
         src, dst, tms = to_dev(src_node_ids, torch.int64), to_dev(dst_node_ids, torch.int64), to_dev(node_interact_times, torch.float64)
         B = src.numel()
         assert dst.numel() == B and tms.numel() == B
@@ -117,6 +125,25 @@ class TGAT(nn.Module):
                                                  src.data_ptr(), dst.data_ptr(), tms.data_ptr(), B, out_src.data_ptr(), out_dst.data_ptr(),
                                                  ws.data_ptr(), ws.numel(), _capi.current_stream_ptr()))
         return out_src, out_dst
+
+    def compute_node_temporal_embeddings(self, node_ids, node_interact_times, current_layer_num: int, num_neighbors: int = 20) -> torch.Tensor:
+        """models/TGAT.py:66-136: the embedding of `node_ids` at `node_interact_times` after `current_layer_num` layers ([n, node_feat_dim]).
+        Layer 0 is the raw node feature row (:85-88); layer l is the l-layer model over the first l conv / merge layers (the recursion only
+        ever descends, :92-110), i.e. one library call with num_layers = l on the nodes as both sides (`recent`: duplicates are computed once)."""
+        assert current_layer_num >= 0                                                      # models/TGAT.py:77
+        if current_layer_num > self.num_layers:
+            raise IndexError("index out of range in temporal_conv_layers")              # ModuleList indexing in the reference (:123)
+        if current_layer_num == 0:
+            self.neighbor_sampler.csr.check_query_ids(node_ids, limit=self.node_raw_features.shape[0])
+            idx = node_ids if isinstance(node_ids, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(node_ids, dtype=np.int64))
+            return self.node_raw_features[idx.to(self.node_raw_features.device)]
+        full = self.num_layers
+        try:
+            self.num_layers = int(current_layer_num)
+            emb, _ = self.compute_src_dst_node_temporal_embeddings(node_ids, node_ids, node_interact_times, num_neighbors=num_neighbors)
+        finally:
+            self.num_layers = full
+        return emb
 
     def last_level_entries(self) -> Tuple[int, int]:
         """(entries over the computed levels, entries actually computed) of the last `recent` call: two-layer models compute every

@@ -85,8 +85,8 @@ def main():
         model.train(); merge.train()
         model.set_neighbor_sampler(train_sampler)
         nb = train.num_interactions // args.batch
-        losses = []
-        for i in D.shard_batch_indices(nb, rank, world):
+
+        def train_step(i):
             sl = slice(i * args.batch, (i + 1) * args.batch)
             src, dst, t = train.src_node_ids[sl], train.dst_node_ids[sl], train.node_interact_times[sl]
             neg = rs.choice(items, size=len(src))
@@ -94,12 +94,9 @@ def main():
             s2, d2 = model.compute_src_dst_node_temporal_embeddings_many(np.stack([src, src]), np.stack([dst, neg]), np.stack([t, t]))
             ps, pd, ns, nd = s2[0], d2[0], s2[1], d2[1]
             pos, ng = merge(ps, pd).squeeze(-1).sigmoid(), merge(ns, nd).squeeze(-1).sigmoid()
-            loss = torch.nn.functional.binary_cross_entropy(torch.cat([pos, ng]), torch.cat([torch.ones_like(pos), torch.zeros_like(ng)]))
-            opt.zero_grad()
-            loss.backward()
-            D.allreduce_gradients(params)
-            opt.step()
-            losses.append(float(loss.detach()))
+            return torch.nn.functional.binary_cross_entropy(torch.cat([pos, ng]), torch.cat([torch.ones_like(pos), torch.zeros_like(ng)]))
+        # every rank takes ceil(nb / world) optimizer steps; a rank without a batch joins the gradient all-reduce with zeros
+        losses = D.train_sharded(train_step, params, opt, nb, rank, world) or [float("nan")]
         m = evaluate(val)
         history.append({"epoch": epoch, "train_loss": float(np.mean(losses)), "val_ap": m["average_precision"], "val_auc": m["roc_auc"]})
         if rank == 0:

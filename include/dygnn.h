@@ -169,10 +169,14 @@ size_t dygnn_dygformer_workspace_bytes_for(const dygnn_dygformer_config* cfg_hos
  * the result of every group is bit-identical to a separate reference call on that group, so several
  * reference calls (e.g. the positive and the negative call of a step, evaluate_models_utils.py:126-136, or
  * several evaluation batches) run as ONE grid that keeps all 256 CUs busy.  G = 0 or G >= batch: one group.
- * impl: 0 = auto (a fused MFMA kernel when the shape is supported, else generic),
+ * impl: 0 = auto (the fused MFMA kernel when the shape is supported, else generic),
  *       1 = generic multi-kernel path (any shape),
- *       2 = fused kernel, wave-pair layout (<= 64 tokens per pair; error if unsupported),
- *       3 = fused kernel, token-owner layout (<= 128 tokens per pair; error if unsupported). */
+ *       3 = fused kernel, token-owner layout (<= 128 tokens per pair; error if unsupported);
+ *       2 (the first fused kernel, superseded) was removed in ABI 11 and is an error.
+ * Node ids: the reference trusts them (an out-of-range id is an IndexError from numpy).  The host mirror raises
+ * that IndexError for numpy inputs and validates the tables once per sampler (every CSR neighbour id < rows of node_feat,
+ * every CSR edge id < rows of edge_feat); the kernels themselves never fault on a bad QUERY id: ids outside
+ * [0, csr.num_nodes) are treated as the padding node 0 (empty history, zero feature row). */
 int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg_host, const dygnn_dygformer_weights* w_host,
                             const void* packed, const dygnn_csr* csr_host,
                             const float* node_feat, const float* edge_feat,

@@ -276,49 +276,6 @@ def run_eval_case(name: str) -> dict:
             "neg_src_first": neg.random_state.randint(0, 10, 1)}          # state check: the next draw after the whole pass
 
 
-def run_nodecls_case(name: str) -> dict:
-    """the reference's evaluate_model_node_classification (evaluate_models_utils.py:160-249) end to end on the CPU"""
-    import contextlib, io
-    from evaluate_models_utils import evaluate_model_node_classification as ref_evaluate      # noqa: E402  (reference)
-    from models.modules import MLPClassifier as RefMLPClassifier                                # noqa: E402  (reference)
-    from utils.DataLoader import get_idx_data_loader as ref_get_idx_data_loader               # noqa: E402  (reference)
-    r = gc.NODECLS_CASES[name]
-    if r["model"] == "DyGFormer":
-        c = gc.build_case(r["graph"]); cfg = c["cfg"]
-    elif r["model"] == "TGAT":
-        c = gc.build_tgat_case(r["graph"]); cfg = c["tgat_cfg"]
-    else:
-        c = gc.build_tgn_case(r["graph"]); cfg = c["tgn_cfg"]
-    d = c["data"]
-    ref_data = RefData(d.src_node_ids, d.dst_node_ids, d.node_interact_times, d.edge_ids, d.labels)
-    sampler = ref_get_neighbor_sampler(ref_data, sample_neighbor_strategy="recent", seed=1)
-    if r["model"] == "DyGFormer":
-        backbone = RefDyGFormer(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"],
-                                channel_embedding_dim=cfg["channel_embedding_dim"], patch_size=cfg["patch_size"], num_layers=cfg["num_layers"],
-                                num_heads=cfg["num_heads"], dropout=0.1, max_input_sequence_length=cfg["max_input_sequence_length"], device="cpu")
-        backbone.load_state_dict({k: torch.from_numpy(v) for k, v in c["params"].items()}, strict=True)
-    elif r["model"] == "TGAT":
-        backbone = RefTGAT(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"], num_layers=cfg["num_layers"],
-                           num_heads=cfg["num_heads"], dropout=0.1, device="cpu")
-        backbone.load_state_dict({k: torch.from_numpy(v) for k, v in c["tgat_params"].items()}, strict=True)
-    else:
-        backbone = RefMemoryModel(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"], model_name="TGN",
-                                  num_layers=cfg["num_layers"], num_heads=cfg["num_heads"], dropout=0.1, device="cpu")
-        sd = backbone.state_dict(); sd.update({k: torch.from_numpy(v) for k, v in c["tgn_params"].items()}); backbone.load_state_dict(sd, strict=True)
-        backbone.memory_bank.__init_memory_bank__()
-    head = RefMLPClassifier(input_dim=172, dropout=0.1)
-    head.load_state_dict({k: torch.from_numpy(v) for k, v in gc.nodecls_classifier_params().items()}, strict=True)
-    model = torch.nn.Sequential(backbone, head)
-    first, last = gc.eval_indices(d.num_interactions)
-    sl = slice(first, last)
-    eval_data = RefData(d.src_node_ids[sl], d.dst_node_ids[sl], d.node_interact_times[sl], d.edge_ids[sl], gc.nodecls_labels(last - first))
-    loader = ref_get_idx_data_loader(indices_list=list(range(last - first)), batch_size=r["batch"], shuffle=False)
-    with contextlib.redirect_stderr(io.StringIO()):
-        loss, metrics = ref_evaluate(model_name=r["model"], model=model, neighbor_sampler=sampler, evaluate_idx_data_loader=loader,
-                                     evaluate_data=eval_data, loss_func=torch.nn.BCELoss(), num_neighbors=cfg.get("num_neighbors", 20), time_gap=2000)
-    return {"total_loss": np.array(loss, dtype=np.float64), "roc_auc": np.array(metrics["roc_auc"], dtype=np.float64)}
-
-
 def run_metric_cases() -> dict:
     """the reference's utils/metrics.py (scikit-learn underneath) and torch's BCELoss (train_link_prediction.py:147 loss_func)
     on the score vectors of tests/golden_cases.py"""
@@ -339,12 +296,8 @@ def run_metric_cases() -> dict:
 def main():
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(8)
-    names = sys.argv[1:] or (list(gc.CASES) + list(gc.TGAT_CASES) + list(gc.TGN_CASES) + ["sampling_" + n for n in gc.SAMPLING_CASES] + ["loader_toy"] + ["grads_" + n for n in gc.GRAD_CASES] + ["tgat_rand_" + n for n in gc.TGAT_RANDOM_CASES] + ["metrics"] + list(gc.EVAL_CASES) + list(gc.NODECLS_CASES))
+    names = sys.argv[1:] or (list(gc.CASES) + list(gc.TGAT_CASES) + list(gc.TGN_CASES) + ["sampling_" + n for n in gc.SAMPLING_CASES] + ["loader_toy"] + ["grads_" + n for n in gc.GRAD_CASES] + ["tgat_rand_" + n for n in gc.TGAT_RANDOM_CASES] + ["metrics"] + list(gc.EVAL_CASES))
     for name in names:
-        if name in gc.NODECLS_CASES:
-            np.savez_compressed(os.path.join(gc.GOLDEN_DIR, name + ".npz"), **run_nodecls_case(name))
-            print(f"{name}: written")
-            continue
         if name in gc.EVAL_CASES:
             np.savez_compressed(os.path.join(gc.GOLDEN_DIR, name + ".npz"), **run_eval_case(name))
             print(f"{name}: written")

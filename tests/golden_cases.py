@@ -245,24 +245,3 @@ EVAL_NEG_SEED = 0
 def eval_indices(num_interactions: int):
     first = int(num_interactions * (1 - EVAL_FRACTION))
     return first, num_interactions
-
-
-# ---- node-classification evaluation (reference evaluate_models_utils.py:160-249): the source embedding of every interaction of the
-# evaluation span goes through an MLPClassifier; labels and classifier weights are seeded here; fixtures nodecls_<model>.npz hold the
-# reference's (total loss, roc_auc).
-NODECLS_CASES = {
-    "nodecls_dygformer": dict(model="DyGFormer", graph="bip_p2_l64", batch=40),
-    "nodecls_tgat": dict(model="TGAT", graph="tgat_bip_l2_k20", batch=40),
-    "nodecls_tgn": dict(model="TGN", graph="tgn_bip_l1_k10", batch=40),
-}
-NODECLS_SEED = 77
-
-
-def nodecls_labels(n: int) -> np.ndarray:
-    return (np.random.RandomState(NODECLS_SEED).random_sample(n) < 0.25).astype(np.float64)
-
-
-def nodecls_classifier_params() -> dict:
-    rs = np.random.RandomState(NODECLS_SEED + 1)
-    shapes = {"fc1.weight": (80, 172), "fc1.bias": (80,), "fc2.weight": (10, 80), "fc2.bias": (10,), "fc3.weight": (1, 10), "fc3.bias": (1,)}
-    return {k: (rs.standard_normal(v) * (0.3 if k.endswith("weight") else 0.05)).astype(np.float32) for k, v in shapes.items()}

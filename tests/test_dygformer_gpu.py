@@ -16,8 +16,7 @@ from tests.parity import close  # plain 1e-4 absolute; observed errors are print
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
-IMPLS = {"generic": 1, "fused": 2, "fused3": 3, "auto": 0}
-FUSED_UNSUPPORTED = {"bip_p8_l512", "bip_p64_l2048"}      # impl 2 (wave-pair kernel): <= 64 tokens and short windows only
+IMPLS = {"generic": 1, "fused3": 3, "auto": 0}
 GENERIC_UNSUPPORTED = {"bip_p64_l2048"}                   # impl 1: 4096 window positions do not fit its LDS staging
 
 
@@ -49,7 +48,7 @@ def case(request):
 def test_forward_matches_golden(case, impl):
     name, c, g, model, merge = case
     model.impl = IMPLS[impl]
-    if (impl == "fused" and name in FUSED_UNSUPPORTED) or (impl == "generic" and name in GENERIC_UNSUPPORTED):
+    if impl == "generic" and name in GENERIC_UNSUPPORTED:
         with pytest.raises(NotImplementedError):          # DYGNN_E_UNSUPPORTED, never a silent fallback
             with torch.no_grad():
                 model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
@@ -135,7 +134,7 @@ def test_wikipedia_scale_batch_against_oracle():
     src, dst, t = data.src_node_ids[idx], data.dst_node_ids[idx], data.node_interact_times[idx]
     with torch.no_grad():
         os_, od = orc.dygformer_forward(params, nf, ef, adj, src, dst, t, 2, 64)
-        for impl in (1, 2, 3):
+        for impl in (1, 3):
             model.impl = impl
             gs, gd = model.compute_src_dst_node_temporal_embeddings(src, dst, t)
             close(gs.cpu().numpy(), os_.numpy(), f"impl {impl} src")
@@ -155,7 +154,7 @@ def test_many_calls_in_one_launch_match_separate_calls():
     src = np.stack([d.src_node_ids[r] for r in rows])
     dst = np.stack([d.dst_node_ids[r] for r in rows])
     t = np.stack([d.node_interact_times[r] for r in rows])
-    for impl in (1, 2, 3):
+    for impl in (1, 3):
         model.impl = impl
         with torch.no_grad():
             many_s, many_d = model.compute_src_dst_node_temporal_embeddings_many(src, dst, t)
@@ -185,7 +184,7 @@ def test_large_timestamps_take_the_libm_cosine_path():
     src, dst, t = data.src_node_ids[idx], data.dst_node_ids[idx], data.node_interact_times[idx]
     with torch.no_grad():
         os_, od = orc.dygformer_forward(params, nf, ef, adj, src, dst, t, 2, 64)
-        for impl in (1, 2, 3):
+        for impl in (1, 3):
             model.impl = impl
             gs, gd = model.compute_src_dst_node_temporal_embeddings(src, dst, t)
             close(gs.cpu().numpy(), os_.numpy(), f"large t, impl {impl} src")

@@ -120,48 +120,3 @@ def test_evaluation_loop_other_loss_function_and_bad_model_name():
     assert len(a) == 3 and np.allclose(np.array(b) / np.array([80, 80, 20]), a, rtol=1e-5)
     with pytest.raises(ValueError):
         evaluate_model_link_prediction("JODIE", evaluate_idx_data_loader=[], loss_func=torch.nn.BCELoss(), **kw)
-
-
-def _build_nodecls(name, dev):
-    import torch
-    from dyglib_amd import MLPClassifier
-    r0 = gc.NODECLS_CASES[name]
-    gc.EVAL_CASES["_tmp_" + name] = dict(model=r0["model"], graph=r0["graph"], batch=r0["batch"])
-    try:
-        r, c, cfg, sampler, model = _build("_tmp_" + name, dev)
-    finally:
-        del gc.EVAL_CASES["_tmp_" + name]
-    head = MLPClassifier(input_dim=172, dropout=0.1)
-    head.load_state_dict({k: torch.from_numpy(v) for k, v in gc.nodecls_classifier_params().items()})
-    model = torch.nn.Sequential(model[0], head.to(dev))
-    return r, c, cfg, sampler, model
-
-
-def test_mlp_classifier_state_dict_matches_reference_shapes():
-    from dyglib_amd import MLPClassifier
-    m = MLPClassifier(172)
-    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: v.shape for k, v in gc.nodecls_classifier_params().items()}
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("name", list(gc.NODECLS_CASES))
-@pytest.mark.parametrize("fuse", [1, 4])
-def test_node_classification_evaluation_matches_reference(name, fuse):
-    """evaluate_model_node_classification against the reference's own run (evaluate_models_utils.py:160-249): mean batch loss within 1e-4
-    relative; ROC AUC over the whole split (135 samples) within one swapped pair (the classifier sees embeddings that agree to ~1e-6)."""
-    import torch
-    from dyglib_amd import Data, evaluate_model_node_classification, get_idx_data_loader
-    r, c, cfg, sampler, model = _build_nodecls(name, "cuda:0")
-    g = gc.load_golden(name)
-    d = c["data"]
-    first, last = gc.eval_indices(d.num_interactions)
-    sl = slice(first, last)
-    eval_data = Data(d.src_node_ids[sl], d.dst_node_ids[sl], d.node_interact_times[sl], d.edge_ids[sl], gc.nodecls_labels(last - first))
-    loader = get_idx_data_loader(list(range(last - first)), r["batch"], shuffle=False)
-    loss, metrics = evaluate_model_node_classification(model_name=r["model"], model=model, neighbor_sampler=sampler, evaluate_idx_data_loader=loader,
-                                                       evaluate_data=eval_data, loss_func=torch.nn.BCELoss(), num_neighbors=cfg.get("num_neighbors", 20),
-                                                       fuse_batches=fuse)
-    assert isinstance(loss, float) and set(metrics) == {"roc_auc"}
-    assert abs(loss - float(g["total_loss"])) <= 1e-4 * max(1.0, float(g["total_loss"]))
-    n_pos = int(gc.nodecls_labels(last - first).sum())
-    assert abs(metrics["roc_auc"] - float(g["roc_auc"])) <= 1.5 / (n_pos * (last - first - n_pos))
