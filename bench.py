@@ -152,8 +152,10 @@ def run_dygformer(wk: DygformerWorkload, steps: int, warmup: int, F: int, rank: 
             ts = torch.cat([wk.t_all[idx], wk.t_all[idx]])
             if ev is not None:
                 ev[0].record(st)
+                wk.model._kernel_events = (ev[2], ev[3])      # recorded by the library right around the fused kernel's launch
             s, d = wk.model.compute_src_dst_node_temporal_embeddings_many(srcs, dsts, ts)      # [2n, B, 172]
             if ev is not None:
+                wk.model._kernel_events = None
                 ev[1].record(st)
             prob = wk.merge.link_probabilities(s.reshape(-1, s.shape[-1]), d.reshape(-1, d.shape[-1])).reshape(2, nsteps, B)
             pos, negp = prob[0], prob[1]
@@ -187,7 +189,13 @@ def run_dygformer(wk: DygformerWorkload, steps: int, warmup: int, F: int, rank: 
     sync_all()
     [a.zero_() for a in metric_accs]
     n_launch = (steps + F - 1) // F
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_launch)]
+    # per timed launch: (call start, call end, kernel start, kernel end).  The kernel pair is recorded by the library on the launch stream
+    # immediately before / after the fused forward (dygnn_dygformer_taps.ev_kernel_*); they are created here by a first record().
+    events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(n_launch)]
+    for evs in events:
+        for e in evs:
+            e.record(streams[0])
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     run_steps(warmup, steps, events, keep_steps=keep)
     sync_all()
@@ -196,13 +204,15 @@ def run_dygformer(wk: DygformerWorkload, steps: int, warmup: int, F: int, rank: 
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    # dominant kernel = the fused forward, one launch per F steps: mean duration of the FULL launches (HIP events on the launch
-    # stream, inside the timed region; they bracket the window-search launches + the fused forward of one call)
+    # dominant kernel = the fused forward, one launch per F steps: mean duration of the FULL launches, from HIP events recorded on the
+    # launch stream inside the timed region right around that kernel's launch (the generic path: around the whole call)
     sizes = [min(F, steps - i * F) for i in range(n_launch)]
     full = [i for i in range(n_launch) if sizes[i] == sizes[0]]
-    launch_ms = float(np.mean([events[i][0].elapsed_time(events[i][1]) for i in full]))
+    impl_fused = wk.model.impl in (0, 3)
+    call_ms = float(np.mean([events[i][0].elapsed_time(events[i][1]) for i in full]))           # window search + fused forward + host gaps
+    launch_ms = float(np.mean([events[i][2].elapsed_time(events[i][3]) for i in full])) if impl_fused else call_ms
     acc = sum(a.cpu().numpy() for a in metric_accs)
-    return dict(elapsed=elapsed, value=steps * B * world / elapsed, launch_ms=launch_ms, steps_per_launch=sizes[0], n_launch=n_launch,
+    return dict(elapsed=elapsed, value=steps * B * world / elapsed, launch_ms=launch_ms, call_ms=call_ms, steps_per_launch=sizes[0], n_launch=n_launch,
                 timed_launches=len(full), mean_auc=float(acc[0] / max(acc[2], 1)), kept=kept, order=order_h[warmup:warmup + steps], streams=len(streams))
 
 
@@ -227,8 +237,9 @@ def dygformer_roofline(wk: DygformerWorkload, res: dict, impl: int) -> dict:
     kern = {1: "generic multi-kernel path"}.get(impl, "k_dygformer_fused3<%d>" % (4 if 2 * ((L + P - 1) // P) <= 64 else 8))
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
-            "kernel": kern + " (+ the window-search launches in front of it)", "flop_per_pair": fpp,
-            "flop_per_launch": flop_per_launch, "ms_per_launch": round(res["launch_ms"], 4), "pairs_per_launch": pairs,
+            "kernel": kern, "flop_per_pair": fpp,
+            "flop_per_launch": flop_per_launch, "ms_per_launch": round(res["launch_ms"], 4), "ms_per_call": round(res["call_ms"], 4),
+            "call": "window-search launches + the kernel + host gaps between them", "pairs_per_launch": pairs,
             "timed_launches": res["timed_launches"]}
 
 

@@ -31,7 +31,12 @@ CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-W
 #           UndefinedBehaviorSanitizer; hipcc leaves the gfx950 code objects unsanitized (GPU ASan needs xnack+, unavailable here).
 #           Driven by tests/test_sanitizers_cpu.py on the CPU box, never loaded by the product path.
 SANITIZE = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-shared-libsan", "-Wno-option-ignored"]
-VARIANTS = {"": [], "stamps": ["-DDYGNN_STAMPS=1"], "asan": SANITIZE}
+VARIANTS = {"": [], "stamps": ["-DDYGNN_STAMPS=1"], "asan": SANITIZE,
+            # A/B arm of the fused DyGFormer kernel (tools/ab_fused3.py): its build-time feature switched off
+            "f3noskip": ["-DF3_KSKIP=0"]}
+for _k, _v in list(os.environ.items()):          # ad-hoc arms: DYGNN_VARIANT_<name>="-DX=1 -DY=2"
+    if _k.startswith("DYGNN_VARIANT_"):
+        VARIANTS[_k[len("DYGNN_VARIANT_"):].lower()] = _v.split()
 LINK_EXTRA = {"asan": ["-fsanitize=address,undefined", "-shared-libsan"]}
 
 

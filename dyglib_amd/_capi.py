@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported first: see module docstring)
 from . import _build
 
 DYGNN_MAX_LAYERS = 8
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -79,7 +79,7 @@ class TgnState(C.Structure):
 
 class DygformerTaps(C.Structure):
     _fields_ = [("seq_lens", C.c_void_p), ("encoder_input", C.c_void_p), ("layer_out", C.c_void_p * DYGNN_MAX_LAYERS),
-                ("phase_cycles", C.c_void_p)]
+                ("phase_cycles", C.c_void_p), ("ev_kernel_start", C.c_void_p), ("ev_kernel_stop", C.c_void_p)]
 
 
 # name -> (restype, argtypes).  Every symbol include/dygnn.h declares; tests check the export list.
@@ -161,6 +161,17 @@ def load() -> C.CDLL:
     if lib.dygnn_abi_version() != ABI_VERSION:
         raise DygnnError(f"{path}: ABI version {lib.dygnn_abi_version()} != {ABI_VERSION}; rebuild (python -m dyglib_amd._build --force)")
     _lib = lib
+    return lib
+
+
+def load_variant(variant: str) -> C.CDLL:
+    """A second, independently loaded build of the library (dyglib_amd/_build.py VARIANTS) next to the default one: the A/B tools time
+    several builds of one kernel in ONE process (cdna_hip_programming.md §5.4 rule 24).  Not used by the product path."""
+    path = _build.build(verbose=False, variant=variant)
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
     return lib
 
 

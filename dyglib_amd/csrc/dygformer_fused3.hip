@@ -21,6 +21,17 @@
 
 #include "dygformer_layout.h"
 
+// Build-time switch (tools/ab_fused3.py builds the other arm with -DF3_KSKIP=0 to A/B it in one process):
+//   F3_KSKIP     the K = 200 products (QKV, FFN W1) spend 2 instead of 4 MFMAs on their last k-chunk (192..207: only 8 real k)
+// Measured and NOT kept (round 2, profiles/r02_fused3_ab.md): a software-pipelined FFN (stream order W1(p+1) before W2(p), GELU of step p
+// issued inside the W1(p+1) block — in chunks between MFMA groups, or whole before / after the block's MFMAs with the two waves of a SIMD at
+// opposite ends): 1.3-1.6 % SLOWER in every arrangement, the two waves of a SIMD already run the block one after the other (the older or
+// prioritised wave takes nearly every matrix-pipe slot), so one GELU of the two is hidden as it is; a static s_setprio 1 for waves 4-7: +-0.2 %;
+// stage barriers every 13 instead of 26 fragments in the FFN with the next group's fragments read before the barrier: slower (twice the barriers).
+#ifndef F3_KSKIP
+#define F3_KSKIP 1
+#endif
+
 namespace dygnn {
 namespace v3 {
 
@@ -56,12 +67,39 @@ __device__ __forceinline__ void mma_group(f4* acc, const f4* a, const f4 b) {
 #pragma unroll
     for (int u = 0; u < N; ++u) acc[u] = mfma(a[u].w, b.w, acc[u]);
 }
+// last k-chunk of a K = 200 product: k = 192..199 packed into TWO MFMAs (b0: k = 192 + {0,4,1,5}[g], b1: k = 192 + {2,6,3,7}[g]);
+// the A fragments of that chunk are packed to match (FragDesc.kmode 1)
+template <int N>
+__device__ __forceinline__ void mma_group2(f4* acc, const f4* a, const float b0, const float b1) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) acc[u] = mfma(a[u].x, b0, acc[u]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) acc[u] = mfma(a[u].y, b1, acc[u]);
+}
+// v = rows 192 + 4g + r of an accumulator-layout tile (g >= 2: zero padding).  v_permlane32_swap moves lanes 0..31 of the second
+// operand into lanes 32..63 of the first: (x, y) -> lanes g = 0,1,2,3 hold rows 192, 196, 193, 197; (z, w) -> 194, 198, 195, 199
+__device__ __forceinline__ void kpack(const f4 v, float& b0, float& b1) {
+    // (scalars first: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 whatever the element — hipcc, ROCm 7.2)
+    const float vx = v.x, vy = v.y, vz = v.z, vw = v.w;
+    const auto r0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, vx), __builtin_bit_cast(unsigned, vy), false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, vz), __builtin_bit_cast(unsigned, vw), false, false);
+    b0 = __builtin_bit_cast(float, r0[0]);
+    b1 = __builtin_bit_cast(float, r1[0]);
+}
 __device__ __forceinline__ f4 ldg4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ f4 lds4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ f4 zero4() { return f4{0.f, 0.f, 0.f, 0.f}; }
-__device__ __forceinline__ void dma_frag(const float* gsrc_lane, float* lds_dst_uniform) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
-                                     (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KiB), no VGPR destination.
+// Written as inline asm on purpose.  With the builtin (__builtin_amdgcn_global_load_lds) hipcc (ROCm 7.2) knows an LDS-DMA is in flight
+// and from then on waits `s_waitcnt lgkmcnt(0)` — not a counted lgkmcnt(N) — before the MFMAs that consume ds_read results: every other
+// MFMA group of every weight loop then stalls for the LDS round trip of the fragments it has just PREFETCHED for the next group (this
+// kernel keeps a DMA in flight all the time).  The asm form is invisible to that bookkeeping; the protocol needs nothing from it: every
+// wave drains its own DMAs with an explicit `s_waitcnt vmcnt(0)` in front of the stage barrier (WStream::advance).
+// The destination is given as a FLOAT OFFSET into the kernel's one dynamic LDS array (which starts at __builtin_amdgcn_groupstaticsize():
+// the kernel has no static LDS), not as a pointer: an addrspacecast of a generic pointer in this position trips an instruction verifier error.
+__device__ __forceinline__ void dma_frag(const float* gsrc_lane, int lds_float_off_uniform) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_groupstaticsize() + 4u * (unsigned)lds_float_off_uniform);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc_lane), "s"(m0v) : "memory", "m0");
 }
 
 // sum over the 16 lanes of a DPP row (= the 16 tokens of a tile, lane & 15), result in every lane: four VALU adds with
@@ -146,7 +184,7 @@ struct Args {
 // ---- the shared weight stream ---------------------------------------------------------------------------------
 struct WStream {
     const float* gsrc;    // stream base + lane*4 (per lane)
-    float* ring;          // LDS ring (wave-uniform)
+    int ring;             // LDS ring: float offset into the dynamic LDS array (wave-uniform)
     int wave, nstages;
     int pos;              // ring slot of the next fragment
     int instage;          // fragments consumed of the current stage
@@ -154,12 +192,12 @@ struct WStream {
     __device__ __forceinline__ void issue(int s) {
         if (s < nstages) {
             const float* srcp = gsrc + (size_t)s * (kStage * kFrag);
-            float* dst = ring + (s & 3) * (kStage * kFrag);
+            const int dst = ring + (s & 3) * (kStage * kFrag);
             dma_frag(srcp + wave * kFrag, dst + wave * kFrag);
             if (wave + 8 < kStage) dma_frag(srcp + (wave + 8) * kFrag, dst + (wave + 8) * kFrag);
         }
     }
-    __device__ __forceinline__ void open(const float* stream, float* ring_, int lane, int wave_, int nstages_) {
+    __device__ __forceinline__ void open(const float* stream, int ring_, int lane, int wave_, int nstages_) {
         gsrc = stream + lane * 4; ring = ring_; wave = wave_; nstages = nstages_;
         pos = 0; instage = 0; issued = 4;
 #pragma unroll
@@ -193,13 +231,13 @@ struct WStream {
 // Diagnostic build (-DDYGNN_STAMPS): every wave accumulates s_memtime ticks per phase category and the last four
 // workgroups of the grid store them: taps.phase_cycles[wg][wave][cat]; cat 31 = total.
 #ifdef DYGNN_STAMPS
-#define TDECL unsigned long long tacc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tk_ = __builtin_amdgcn_s_memtime(); const unsigned long long tk0_ = tk_
+#define TDECL unsigned long long tacc_[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tk_ = __builtin_amdgcn_s_memtime(); const unsigned long long tk0_ = tk_
 #define TACC(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc_[i] += t_ - tk_; tk_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define TSTORE()                                                                                   \
     do {                                                                                           \
         if (a.stamps != nullptr && lane == 0 && blockIdx.x + 4 >= gridDim.x) {                     \
             unsigned long long* o_ = a.stamps + ((size_t)(blockIdx.x + 4 - gridDim.x) * 8 + wave) * 32;   \
-            for (int i_ = 0; i_ < 16; ++i_) o_[i_] = tacc_[i_];                                    \
+            for (int i_ = 0; i_ < 24; ++i_) o_[i_] = tacc_[i_];                                    \
             o_[31] = tk_ - tk0_;                                                                   \
         }                                                                                          \
     } while (0)
@@ -208,7 +246,8 @@ struct WStream {
 #define TACC(i) do { } while (0)
 #define TSTORE() do { } while (0)
 #endif
-enum { T_WIN = 0, T_PROJ, T_LN, T_QKV, T_QKVBAR, T_ATTN, T_OPROJ, T_FFN, T_POOL, T_MISC, T_POOL1, T_POOL2, T_PNODE, T_PTIME, T_PEDGE, T_PCOOC };
+enum { T_WIN = 0, T_PROJ, T_LN, T_QKV, T_QKVBAR, T_ATTN, T_OPROJ, T_FFN, T_POOL, T_MISC, T_POOL1, T_POOL2, T_PNODE, T_PTIME, T_PEDGE, T_PCOOC,
+       T_F_W1 = 16, T_F_GELU, T_F_ADV1, T_F_W2, T_F_ADV2 };      // FFN sub-phases
 
 // LayerNorm of the register-resident X^T (two-pass, biased variance, eps 1e-5); gamma/beta from LDS
 __device__ __forceinline__ void layernorm(f4 (&xn)[kNT], const f4 (&x)[kNT], const float* gamma, const float* beta, int g) {
@@ -241,7 +280,7 @@ __device__ __forceinline__ void layernorm(f4 (&xn)[kNT], const f4 (&x)[kNT], con
 
 // acc[7] += W(7 tiles of one head's q, k or v) . xn : 13 stream steps of 7 fragments [k-chunk][tile], each multiplied
 // as sub-groups of 4 and 3 tiles whose fragments are read one sub-group ahead (8 fragments live instead of 14)
-__device__ __forceinline__ void qkv_group(f4 (&acc)[7], const f4 (&xn)[kNT], WStream& ws, const float* ringl, bool active) {
+__device__ __forceinline__ void qkv_group(f4 (&acc)[7], const f4 (&xn)[kNT], const float xk0, const float xk1, WStream& ws, const float* ringl, bool active) {
     f4 fs[2][4];
     ws.fit(7);
     if (active) {
@@ -254,7 +293,7 @@ __device__ __forceinline__ void qkv_group(f4 (&acc)[7], const f4 (&xn)[kNT], WSt
 #pragma unroll
             for (int u = 0; u < 3; ++u) fs[1][u] = lds4(ringl + (ws.pos + 4 + u) * kFrag);
             __builtin_amdgcn_sched_barrier(0);
-            mma_group<4>(&acc[0], fs[0], xn[kc]);
+            if (F3_KSKIP && kc == kKC - 1) mma_group2<4>(&acc[0], fs[0], xk0, xk1); else mma_group<4>(&acc[0], fs[0], xn[kc]);
             __builtin_amdgcn_sched_barrier(0);
             if (kc + 1 < kKC) {
                 const int p1 = ws.next_pos(7, 7);
@@ -262,11 +301,59 @@ __device__ __forceinline__ void qkv_group(f4 (&acc)[7], const f4 (&xn)[kNT], WSt
                 for (int u = 0; u < 4; ++u) fs[0][u] = lds4(ringl + (p1 + u) * kFrag);
             }
             __builtin_amdgcn_sched_barrier(0);
-            mma_group<3>(&acc[4], fs[1], xn[kc]);
+            if (F3_KSKIP && kc == kKC - 1) mma_group2<3>(&acc[4], fs[1], xk0, xk1); else mma_group<3>(&acc[4], fs[1], xn[kc]);
             __builtin_amdgcn_sched_barrier(0);
         }
         ws.advance(7);
         if (kc + 1 < kKC) ws.fit(7);
+    }
+}
+
+
+// ---- FFN blocks: one block = the 26 fragments of one product of one step, at ring position 0 or 26.
+__device__ __forceinline__ void gelu_tiles(f4 (&t)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        t[u].x = gelu_erf(t[u].x); t[u].y = gelu_erf(t[u].y); t[u].z = gelu_erf(t[u].z); t[u].w = gelu_erf(t[u].w);   // DyGFormer.py:458
+    }
+}
+// First product: h[2] (two 16-wide hidden tiles) = b1 + W1 . LN(x); 13 k-chunks of two fragments [k-chunk][tile] read one chunk ahead.
+__device__ __forceinline__ void ffn_w1(f4 (&h)[2], const f4 (&xn)[kNT], const float xk0, const float xk1, const float* abuf, const float* b1p, const int g) {
+    h[0] = lds4(b1p + 4 * g);
+    h[1] = lds4(b1p + 16 + 4 * g);
+    f4 sa[2][2];
+    sa[0][0] = lds4(abuf); sa[0][1] = lds4(abuf + kFrag);
+#pragma unroll
+    for (int kc = 0; kc < kKC; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < kKC) {
+            sa[cur ^ 1][0] = lds4(abuf + (size_t)(2 * (kc + 1)) * kFrag);
+            sa[cur ^ 1][1] = lds4(abuf + (size_t)(2 * (kc + 1) + 1) * kFrag);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (F3_KSKIP && kc == kKC - 1) mma_group2<2>(h, sa[cur], xk0, xk1); else mma_group<2>(h, sa[cur], xn[kc]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// Second product: acc (13 model-dim tiles) += W2[:, the two hidden tiles] . h; fragments [tile u][n-tile i] in sub-groups (4,3,3,3)
+// read one sub-group ahead
+__device__ __forceinline__ void ffn_w2(f4 (&acc)[kNT], const f4 (&h)[2], const float* bbuf) {
+    f4 fs[2][4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) fs[0][v] = lds4(bbuf + (size_t)v * kFrag);
+#pragma unroll
+    for (int gi = 0; gi < 8; ++gi) {
+        const int u = gi >> 2, q = gi & 3;
+        const int i0 = q == 0 ? 0 : 4 + 3 * (q - 1), n = q == 0 ? 4 : 3;
+        if (gi + 1 < 8) {
+            const int u2 = (gi + 1) >> 2, q2 = (gi + 1) & 3;
+            const int j0 = q2 == 0 ? 0 : 4 + 3 * (q2 - 1), n2 = q2 == 0 ? 4 : 3;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) if (v < n2) fs[(gi + 1) & 1][v] = lds4(bbuf + (size_t)(u2 * 13 + j0 + v) * kFrag);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (n == 4) mma_group<4>(&acc[i0], fs[gi & 1], h[u]); else mma_group<3>(&acc[i0], fs[gi & 1], h[u]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -308,15 +395,15 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
     // ---- weights start moving at once: the first four stages of the layer stream into the ring, the first slab of
     // projection fragments into the K/V region behind the window arrays (all of it lands during the window phase)
     WStream ws;
-    if (!a.slab_in_ring) ws.open(a.stream, lds + kLdsRing, lane, wave, a.nstages);
+    if (!a.slab_in_ring) ws.open(a.stream, kLdsRing, lane, wave, a.nstages);
     const float* ringl = lds + kLdsRing + lane * 4;
-    float* slab = a.slab_in_ring ? lds + kLdsRing : lds + a.scr_floats;
-    const float* slabl = slab + lane * 4;
+    const int slab_off = a.slab_in_ring ? kLdsRing : a.scr_floats;
+    const float* slabl = lds + slab_off + lane * 4;
     const int slab_frags = 4 * a.slab_chunks;
     auto load_slab = [&](int k) {
         const int f0 = k * slab_frags;
         const int n = a.proj_frags - f0 < slab_frags ? a.proj_frags - f0 : slab_frags;
-        for (int f = wave; f < n; f += 8) dma_frag(a.projw + (size_t)(f0 + f) * kFrag + lane * 4, slab + (size_t)f * kFrag);
+        for (int f = wave; f < n; f += 8) dma_frag(a.projw + (size_t)(f0 + f) * kFrag + lane * 4, slab_off + f * kFrag);
     };
     load_slab(0);
     float* tws = lds + kLdsMisc + kMiscFloats;      // time-encoder w | b
@@ -548,23 +635,23 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
     float* Vb = lds + kLdsV;
     float* misc = lds + kLdsMisc;
 
+    if (a.slab_in_ring) {        // the ring was the projection slab until now: start the layer stream (one exposed DMA latency).  Outside the
+        ws.open(a.stream, kLdsRing, lane, wave, a.nstages);      // layer loop: inside it the compiler kept the eight DMA addresses live (spilled)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     for (int l = 0; l < a.NL; ++l) {
         const LayerP& W = a.layer[l];
         TACC(T_MISC);
         float* b1s = misc + kMiscB1 + (l & 1) * kHid;
         for (int i = tid; i < kHid; i += 512) b1s[i] = W.b1[i];
-        if (l == 0) {
-            if (a.slab_in_ring) {        // the ring was the projection slab until now: start the layer stream (one exposed DMA latency)
-                ws.open(a.stream, lds + kLdsRing, lane, wave, a.nstages);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();             // the re-zeroing of K/V above is complete before the first K/V rows are written
-        }
+        if (l == 0) __syncthreads();     // the re-zeroing of K/V above is complete before the first K/V rows are written
 
         f4 xn[kNT];
         ws.fit(2);                       // LN0 gamma, beta: two vector fragments
         if (active) layernorm(xn, x, lds + kLdsRing + ws.pos * kFrag, lds + kLdsRing + (ws.pos + 1) * kFrag, g);
         ws.advance(2);
+        float xk0 = 0.f, xk1 = 0.f;      // LN(x) rows 192..199 as the two packed B operands of the last k-chunk
+        if (F3_KSKIP) kpack(xn[kKC - 1], xk0, xk1);
         TACC(T_LN);
 
 #pragma unroll 1
@@ -577,7 +664,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
 #pragma unroll
                 for (int j = 0; j < 7; ++j) qa[j] = lds4(bq + 16 * j);
                 ws.advance(1);
-                qkv_group(qa, xn, ws, ringl, active);
+                qkv_group(qa, xn, xk0, xk1, ws, ringl, active);
 #pragma unroll
                 for (int j = 0; j < 7; ++j) qa[j] = qa[j] * a.qscale;
             }
@@ -589,7 +676,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
 #pragma unroll
                 for (int j = 0; j < 7; ++j) acc[j] = lds4(bk + 16 * j);
                 ws.advance(1);
-                qkv_group(acc, xn, ws, ringl, active);
+                qkv_group(acc, xn, xk0, xk1, ws, ringl, active);
                 // every wave passed a stream barrier since its last read of the previous head's K/V (the out-projection
                 // and the Q group lie in between), so the rows can be overwritten
                 if (active) {
@@ -653,20 +740,24 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                 for (int kt = 0; kt < TPW; ++kt) sa[kt] *= inv;
                 // O^T[d][query] = sum_key V[key][d] * P^T[key][query]  (rows >= 100 are junk x zero weight columns)
                 {
-                    auto load_v = [&](f4 (&va)[7], int kt) {
+                    // V tiles as the A operand: sub-steps (key tile kt, d-tiles 0..3 | 4..6), read one sub-step ahead (8 fragments live, not 14)
+                    auto load_v = [&](f4 (&va)[4], int kt, int j0, int n) {
 #pragma unroll
-                        for (int j = 0; j < 7; ++j) {
-                            const float* vp = Vb + (tokbase + 16 * kt + 4 * g) * kKV + 16 * j + c;
-                            va[j].x = vp[0]; va[j].y = vp[kKV]; va[j].z = vp[2 * kKV]; va[j].w = vp[3 * kKV];
+                        for (int j = 0; j < 4; ++j) {
+                            if (j < n) {
+                                const float* vp = Vb + (tokbase + 16 * kt + 4 * g) * kKV + 16 * (j0 + j) + c;
+                                va[j].x = vp[0]; va[j].y = vp[kKV]; va[j].z = vp[2 * kKV]; va[j].w = vp[3 * kKV];
+                            }
                         }
                     };
-                    f4 va[2][7];
-                    load_v(va[0], 0);
+                    f4 va[2][4];
+                    load_v(va[0], 0, 0, 4);
 #pragma unroll
-                    for (int kt = 0; kt < TPW; ++kt) {
-                        if (kt + 1 < TPW) load_v(va[(kt + 1) & 1], kt + 1);
+                    for (int st = 0; st < 2 * TPW; ++st) {
+                        const int kt = st >> 1, half = st & 1;
+                        if (st + 1 < 2 * TPW) load_v(va[(st + 1) & 1], (st + 1) >> 1, ((st + 1) & 1) ? 4 : 0, ((st + 1) & 1) ? 3 : 4);
                         __builtin_amdgcn_sched_barrier(0);
-                        mma_group<7>(oa, va[kt & 1], sa[kt]);
+                        if (half == 0) mma_group<4>(&oa[0], va[st & 1], sa[kt]); else mma_group<3>(&oa[4], va[st & 1], sa[kt]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -723,64 +814,31 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
         ws.fit(2);
         if (active) layernorm(xn, x, lds + kLdsRing + ws.pos * kFrag, lds + kLdsRing + (ws.pos + 1) * kFrag, g);
         ws.advance(2);
+        if (F3_KSKIP) kpack(xn[kKC - 1], xk0, xk1);
         TACC(T_LN);
-        f4 y[kNT];
-#pragma unroll
-        for (int i = 0; i < kNT; ++i) y[i] = zero4();
         ws.align26();
+        // W1(p) | W2(p) per step; W2 accumulates straight into the residual registers (no separate FFN accumulator: 52 VGPRs fewer)
 #pragma unroll 1
         for (int p = 0; p < 25; ++p) {
             f4 h[2];
             if (active) {
-                const float* abuf = ringl + ws.pos * kFrag;
-                h[0] = lds4(b1s + 32 * p + 4 * g);
-                h[1] = lds4(b1s + 32 * p + 16 + 4 * g);
-                f4 sa[2][2];
-                sa[0][0] = lds4(abuf); sa[0][1] = lds4(abuf + kFrag);
-#pragma unroll
-                for (int kc = 0; kc < kKC; ++kc) {
-                    const int cur = kc & 1;
-                    if (kc + 1 < kKC) {
-                        sa[cur ^ 1][0] = lds4(abuf + (size_t)(2 * (kc + 1)) * kFrag);
-                        sa[cur ^ 1][1] = lds4(abuf + (size_t)(2 * (kc + 1) + 1) * kFrag);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma_group<2>(h, sa[cur], xn[kc]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    h[u].x = gelu_erf(h[u].x); h[u].y = gelu_erf(h[u].y); h[u].z = gelu_erf(h[u].z); h[u].w = gelu_erf(h[u].w);   // DyGFormer.py:458
-                }
+                ffn_w1(h, xn, xk0, xk1, ringl + ws.pos * kFrag, b1s + 32 * p, g);
+                TACC(T_F_W1);
+                gelu_tiles(h);
+                TACC(T_F_GELU);
             }
             ws.advance(26);
-            if (active) {
-                const float* bbuf = ringl + ws.pos * kFrag;
-                f4 fs[2][4];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) fs[0][v] = lds4(bbuf + (size_t)v * kFrag);
-#pragma unroll
-                for (int gi = 0; gi < 8; ++gi) {
-                    const int u = gi >> 2, q = gi & 3;
-                    const int i0 = q == 0 ? 0 : 4 + 3 * (q - 1), n = q == 0 ? 4 : 3;
-                    if (gi + 1 < 8) {
-                        const int u2 = (gi + 1) >> 2, q2 = (gi + 1) & 3;
-                        const int j0 = q2 == 0 ? 0 : 4 + 3 * (q2 - 1), n2 = q2 == 0 ? 4 : 3;
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) if (v < n2) fs[(gi + 1) & 1][v] = lds4(bbuf + (size_t)(u2 * 13 + j0 + v) * kFrag);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (n == 4) mma_group<4>(&y[i0], fs[gi & 1], h[u]); else mma_group<3>(&y[i0], fs[gi & 1], h[u]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+            TACC(T_F_ADV1);
+            if (active) ffn_w2(x, h, ringl + ws.pos * kFrag);
+            TACC(T_F_W2);
             ws.advance(26);
+            TACC(T_F_ADV2);
         }
         ws.fit(1);
         {
             const float* b2 = lds + kLdsRing + ws.pos * kFrag + 4 * g;
 #pragma unroll
-            for (int i = 0; i < kNT; ++i) x[i] = x[i] + (y[i] + lds4(b2 + 16 * i));
+            for (int i = 0; i < kNT; ++i) x[i] = x[i] + lds4(b2 + 16 * i);
         }
         ws.advance(1);
         TACC(T_FFN);
@@ -852,6 +910,7 @@ struct FragDesc {
     int ld;               // matrix fragment: row stride; -1: vector fragment, element e = src[c0 + e] for e < rmax
     int r0, rmax;         // element (c,g,t): row = r0 + c, valid iff 0 <= row < rmax
     int c0, cmax;         //                  col = c0 + 4g + t, valid iff col < cmax
+    int kmode;            // 1: last chunk of a K = 200 product, 8 real k in two MFMAs: t < 2: col = c0 + {0,4,1,5}[g] + 2t, t >= 2: zero (mma_group2)
 };
 
 __global__ void k_pack_stream(const FragDesc* __restrict__ desc, int64_t nfrag, float* __restrict__ dst) {
@@ -860,7 +919,9 @@ __global__ void k_pack_stream(const FragDesc* __restrict__ desc, int64_t nfrag, 
     const int t = idx & 3, lane = (idx >> 2) & 63;
     const FragDesc d = desc[idx >> 8];
     const int c = lane & 15, g = lane >> 4;
-    const int row = d.r0 + c, col = d.c0 + 4 * g + t;
+    const int row = d.r0 + c;
+    int col = d.c0 + 4 * g + t;
+    if (d.kmode == 1) col = t < 2 ? d.c0 + (g & 1) * 4 + (g >> 1) + 2 * t : d.cmax;
     float v = 0.f;
     if (d.src != nullptr) {
         if (d.ld < 0) { const int e = (int)(idx & 255); if (e < d.rmax) v = d.src[d.c0 + e]; }
@@ -879,10 +940,10 @@ __global__ void k_pack_vec3(const float* __restrict__ src, int n_valid, int src_
 struct StreamBuilder {
     std::vector<FragDesc> frags;
     int pos = 0;
-    void pad(int n) { for (int i = 0; i < n; ++i) frags.push_back(FragDesc{nullptr, 0, 0, 0, 0, 0}); pos = (pos + n) % kRing; }
+    void pad(int n) { for (int i = 0; i < n; ++i) frags.push_back(FragDesc{nullptr, 0, 0, 0, 0, 0, 0}); pos = (pos + n) % kRing; }
     void fit(int n) { if (pos + n > kRing) pad(kRing - pos); }
     void align26() { if (pos != 0 && pos != 26) pad(pos < 26 ? 26 - pos : kRing - pos); }
-    void put(const float* src, int ld, int r0, int rmax, int c0, int cmax) { frags.push_back(FragDesc{src, ld, r0, rmax, c0, cmax}); pos = (pos + 1) % kRing; }
+    void put(const float* src, int ld, int r0, int rmax, int c0, int cmax, int kmode = 0) { frags.push_back(FragDesc{src, ld, r0, rmax, c0, cmax, kmode}); pos = (pos + 1) % kRing; }
     void put_vec(const float* src, int off, int n) { put(src, -1, 0, n, off, 0); }     // floats [0, n) of the fragment = src[off ..]
 };
 
@@ -901,7 +962,7 @@ static void build_stream(const Dims& d, const dygnn_dygformer_weights* w, Stream
                 sb.fit(7);
                 for (int kc = 0; kc < kKC; ++kc) {
                     for (int j = 0; j < 7; ++j)
-                        sb.put(L.in_proj_weight + (size_t)part * kD * kD, kD, kHD * h + 16 * j, kHD * (h + 1), 16 * kc, kD);
+                        sb.put(L.in_proj_weight + (size_t)part * kD * kD, kD, kHD * h + 16 * j, kHD * (h + 1), 16 * kc, kD, F3_KSKIP && kc == kKC - 1);
                     if (kc + 1 < kKC) sb.fit(7);
                 }
             }
@@ -917,12 +978,15 @@ static void build_stream(const Dims& d, const dygnn_dygformer_weights* w, Stream
         sb.put_vec(L.norm1_weight, 0, kD);
         sb.put_vec(L.norm1_bias, 0, kD);
         sb.align26();
-        for (int p = 0; p < 25; ++p) {
+        auto put_w1 = [&](int p) {
             for (int kc = 0; kc < kKC; ++kc)
-                for (int u = 0; u < 2; ++u) sb.put(L.ffn0_weight, kD, 16 * (2 * p + u), kHid, 16 * kc, kD);
+                for (int u = 0; u < 2; ++u) sb.put(L.ffn0_weight, kD, 16 * (2 * p + u), kHid, 16 * kc, kD, F3_KSKIP && kc == kKC - 1);
+        };
+        auto put_w2 = [&](int p) {
             for (int u = 0; u < 2; ++u)
                 for (int i = 0; i < kNT; ++i) sb.put(L.ffn1_weight, kHid, 16 * i, kD, 16 * (2 * p + u), kHid);
-        }
+        };
+        for (int p = 0; p < 25; ++p) { put_w1(p); put_w2(p); }
         sb.fit(1);
         sb.put_vec(L.ffn1_bias, 0, kD);
     }
@@ -1099,9 +1163,11 @@ int forward_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_
     // per device and cheap: set on every call (a process may drive several GPUs, or call from several threads)
     DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    if (taps && taps->ev_kernel_start) DYGNN_HIP(hipEventRecord(static_cast<hipEvent_t>(taps->ev_kernel_start), s));
     if (f.np == 2) hipLaunchKernelGGL(k_dygformer_fused3<4>, dim3((unsigned)((B + 1) / 2)), dim3(512), kLdsBytes, s, a);
     else hipLaunchKernelGGL(k_dygformer_fused3<8>, dim3((unsigned)B), dim3(512), kLdsBytes, s, a);
     DYGNN_LAUNCH_CHECK();
+    if (taps && taps->ev_kernel_stop) DYGNN_HIP(hipEventRecord(static_cast<hipEvent_t>(taps->ev_kernel_stop), s));
     return DYGNN_OK;
 }
 

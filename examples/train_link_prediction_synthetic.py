@@ -63,6 +63,7 @@ def main():
     opt = torch.optim.Adam(params, lr=args.lr)
     rs = np.random.RandomState(0)
     items = np.unique(full.dst_node_ids)
+    train_items = np.unique(train.dst_node_ids)      # training negatives come from the TRAINING graph's destinations (train_link_prediction.py:95-96)
 
     def evaluate(split):
         model.eval(); merge.eval()
@@ -89,7 +90,7 @@ def main():
         def train_step(i):
             sl = slice(i * args.batch, (i + 1) * args.batch)
             src, dst, t = train.src_node_ids[sl], train.dst_node_ids[sl], train.node_interact_times[sl]
-            neg = rs.choice(items, size=len(src))
+            neg = rs.choice(train_items, size=len(src))
             # the positive and the negative call of the step (train_link_prediction.py:229-239) as one set: one dense pass when they pad alike
             s2, d2 = model.compute_src_dst_node_temporal_embeddings_many(np.stack([src, src]), np.stack([dst, neg]), np.stack([t, t]))
             ps, pd, ns, nd = s2[0], d2[0], s2[1], d2[1]

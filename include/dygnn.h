@@ -151,6 +151,9 @@ typedef struct dygnn_dygformer_taps {
     float*   layer_out[DYGNN_MAX_LAYERS];
     uint64_t* phase_cycles;                          /* diagnostic builds (-DDYGNN_STAMPS) only:
                                                         [4 workgroups][8 waves][32] s_memtime stamps */
+    void*    ev_kernel_start;                        /* hipEvent_t (or NULL): recorded on `stream` immediately before / after the  */
+    void*    ev_kernel_stop;                         /* launch of the dominant kernel of the call (the fused forward), so a caller  */
+                                                     /* can time THAT kernel, not the call (bench.py's roofline line)               */
 } dygnn_dygformer_taps;
 
 /* Kernel-ready copy of the weights (transposed / MFMA-fragment order, co-occurrence LUT).

@@ -39,7 +39,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_capi.DygformerConfig) == 8 * 4
     assert C.sizeof(_capi.EncoderLayerWeights) == 12 * 8
     assert C.sizeof(_capi.DygformerWeights) == (14 + 12 * _capi.DYGNN_MAX_LAYERS + 2) * 8
-    assert C.sizeof(_capi.DygformerTaps) == (3 + _capi.DYGNN_MAX_LAYERS) * 8
+    assert C.sizeof(_capi.DygformerTaps) == (5 + _capi.DYGNN_MAX_LAYERS) * 8
 
 
 @pytest.mark.parametrize("name", ["bip_p2_l64", "gen_p1_l32"])

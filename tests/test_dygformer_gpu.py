@@ -1,9 +1,11 @@
 """GPU parity of DyGFormer.compute_src_dst_node_temporal_embeddings through the C ABI.
 
 Tolerance: BASELINE.json's north_star asks for fp32 embeddings within 1e-4 of the reference CPU
-path.  Every comparison below is a plain absolute 1e-4 (tests/parity.py), also on the L=512 stress
-case whose embeddings reach magnitude ~20; the largest observed error per label is printed at the
-end of the run."""
+path.  Embeddings and link probabilities — the outputs of the path — are held to a plain absolute
+1e-4 (tests/parity.py), also on the L=512 stress case whose embeddings reach magnitude ~20.  The
+internal taps (encoder input, per-layer residual stream) reach magnitude ~140 there, where one
+float32 ulp is 1.5e-5: they use 1e-4 * max(1, max|ref|).  The largest observed error per label is
+printed at the end of the run."""
 import numpy as np
 import pytest
 import torch
@@ -11,7 +13,7 @@ import torch
 from dyglib_amd import synthetic as syn
 from oracle import dygformer_oracle as orc
 from tests import golden_cases as gc
-from tests.parity import close  # plain 1e-4 absolute; observed errors are printed at the end of the run
+from tests.parity import close, close_scaled  # embeddings / probabilities: plain 1e-4 absolute; internal taps (magnitude up to ~140): scaled
 
 pytestmark = pytest.mark.gpu
 
@@ -67,9 +69,9 @@ def test_forward_matches_golden(case, impl):
     P = c["cfg"]["patch_size"]
     T = (S_s + S_d) // P
     R = gc.TAP_ROWS
-    close(taps["encoder_input"][:R, :T].cpu().numpy(), g["encoder_input_rows"], f"{name}/{impl} encoder input")
+    close_scaled(taps["encoder_input"][:R, :T].cpu().numpy(), g["encoder_input_rows"], f"{name}/{impl} encoder input (internal tap, scaled bar)")
     for l in range(2):
-        close(taps["layer_outputs"][l][:R, :T].cpu().numpy(), g[f"layer{l}_rows"], f"{name}/{impl} layer {l}")
+        close_scaled(taps["layer_outputs"][l][:R, :T].cpu().numpy(), g[f"layer{l}_rows"], f"{name}/{impl} layer {l} (internal tap, scaled bar)")
     close(se.cpu().numpy(), g["src_emb"], f"{name}/{impl} src emb")
     close(de.cpu().numpy(), g["dst_emb"], f"{name}/{impl} dst emb")
     close(nse.cpu().numpy(), g["neg_src_emb"], f"{name}/{impl} neg src emb")

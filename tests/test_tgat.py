@@ -72,8 +72,18 @@ def test_hip_matches_golden(case):
     close(ns.cpu().numpy(), g["neg_src_emb"], name + " neg src")
     close(nd.cpu().numpy(), g["neg_dst_emb"], name + " neg dst")
     assert torch.equal(s, s2) and torch.equal(d, d2)
-    with pytest.raises(AssertionError):
+    with pytest.raises(AssertionError), torch.no_grad():
         m.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"], num_neighbors=0)     # utils/utils.py:157
+    with pytest.raises(NotImplementedError):       # autograd recording: no silent graph-less result (the HIP path has no TGAT backward)
+        m.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"], num_neighbors=k)
+    with pytest.raises(IndexError), torch.no_grad():   # out-of-range id on the numpy API: IndexError like the reference's indexing
+        m.compute_src_dst_node_temporal_embeddings(np.array([10 ** 6]), c["dst"][:1], c["times"][:1], num_neighbors=k)
+    # models/TGAT.py:66-136: the layer-wise entry point; layer 0 = raw features, top layer = the source side of the pair call
+    with torch.no_grad():
+        e0 = m.compute_node_temporal_embeddings(c["src"], c["times"], current_layer_num=0, num_neighbors=k)
+        eL = m.compute_node_temporal_embeddings(c["src"], c["times"], current_layer_num=m.num_layers, num_neighbors=k)
+    assert torch.equal(e0.cpu(), torch.from_numpy(c["node_feat"])[torch.from_numpy(c["src"])])
+    assert torch.equal(eL, s)
 
 
 @pytest.mark.gpu

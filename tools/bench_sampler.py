@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stage-level measurement of the neighbour-lookup kernels (sampler.hip, cooccurrence.hip) through the C ABI:
-queries/s and algorithmic HBM GB/s (DESIGN.md §4.1 byte model) against the 8 TB/s HBM3E peak, on the Wikipedia- and
+queries/s and algorithmic HBM GB/s (SURVEY §8d byte model: 8*ceil(log2(deg+1)) probe bytes + 16 B per window entry of this CSR + outputs) against the 8 TB/s HBM3E peak, on the Wikipedia- and
 Reddit-shaped synthetic graphs.  The reference's get_historical_neighbors runs 149 k queries/s on the CPU.
     python tools/bench_sampler.py [--queries 2000000]
 Prints one JSON line per (graph, kernel)."""
@@ -48,7 +48,7 @@ for gname, (U, I, E) in {"wikipedia": (8227, 1000, 157474), "reddit": (10000, 98
     times = torch.from_numpy(times_h).to(dev)
     n = nodes.numel()
     deg = (s.csr.indptr[nodes_h + 1] - s.csr.indptr[nodes_h]).astype(np.float64)
-    probes = np.maximum(1, np.ceil(np.log(deg + 1) / np.log(64)))             # 64-ary search: dependent round trips
+    probe_bytes = 8 * np.ceil(np.log2(deg + 1))                              # binary-search probes, 8 B each
     lib = s._lib
     csr = s.csr.on_device(dev)
     st = _capi.current_stream_ptr()
@@ -59,7 +59,7 @@ for gname, (U, I, E) in {"wikipedia": (8227, 1000, 157474), "reddit": (10000, 98
         sec = timed(lambda: _capi.check(lib.dygnn_sample_recent(csr, nodes.data_ptr(), times.data_ptr(), n, k, on.data_ptr(), oe.data_ptr(),
                                                                    ot.data_ptr(), st)), args.reps)
         hist = np.minimum(deg, k)
-        algo = float((8 * 64 * probes).sum() + 16 * hist.sum() + 20.0 * k * n + 16 * n)
+        algo = float(probe_bytes.sum() + 16 * hist.sum() + 20.0 * k * n + 16 * n)
         print(json.dumps({"graph": gname, "kernel": f"dygnn_sample_recent k={k}", "queries": n, "queries_per_s": round(n / sec),
                           "algorithmic_GBps": round(algo / sec / 1e9, 1), "frac_of_hbm_peak": round(algo / sec / HBM_PEAK, 4),
                           "ms": round(sec * 1e3, 3)}))
@@ -78,7 +78,7 @@ for gname, (U, I, E) in {"wikipedia": (8227, 1000, 157474), "reddit": (10000, 98
                                           eids.data_ptr(), ts.data_ptr(), st))
     sec = timed(windows, args.reps)
     hist = np.minimum(deg, L - 1)
-    algo = float((8 * 64 * probes).sum() + 16 * hist.sum() + 20.0 * S * n + 16 * n + 12 * n)
+    algo = float(probe_bytes.sum() + 16 * hist.sum() + 20.0 * S * n + 16 * n + 12 * n)
     print(json.dumps({"graph": gname, "kernel": "dygnn_window_lengths + dygnn_window_fill (L=64)", "queries": n, "queries_per_s": round(n / sec),
                       "algorithmic_GBps": round(algo / sec / 1e9, 1), "frac_of_hbm_peak": round(algo / sec / HBM_PEAK, 4), "ms": round(sec * 1e3, 3)}))
     npair = n // 2

@@ -36,12 +36,16 @@ torch.cuda.synchronize()
 st = taps["phase_cycles"].cpu().numpy().astype(np.int64)      # [4 wg][8 waves][32]
 if model.impl == 3:
     cats = ["windows+counts", "projection", "layernorm", "QKV (+K/V store)", "barrier after K/V", "attention (S,softmax,PV)",
-            "out-projection", "FFN", "mean+output layer", "misc (param copies, taps)", "pool shuffles", "pool barrier", "proj node", "proj time", "proj edge", "proj cooc"]
+            "out-projection", "FFN", "mean+output layer", "misc (param copies, taps)", "pool shuffles", "pool barrier", "proj node", "proj time", "proj edge", "proj cooc",
+            "FFN: W1 MFMAs", "FFN: GELU", "FFN: barrier+refill after W1", "FFN: W2 MFMAs", "FFN: barrier+refill after W2"]
     tot = st[:, :, 31].astype(np.float64)
     print(f"total ticks per wave: mean {tot.mean():.0f} (min {tot.min():.0f} max {tot.max():.0f})")
     for i, nm in enumerate(cats):
         v = st[:, :, i].astype(np.float64)
         print(f"{nm:28s} {v.mean():12.0f} {100 * v.mean() / tot.mean():6.1f}%   (per-wave min {v.min():.0f} max {v.max():.0f})")
+    print("per wave (mean over the 4 stamped workgroups), waves 0..7:")
+    for i in (3, 6, 16, 17, 18, 19, 20):
+        print(f"{cats[i]:28s} " + " ".join(f"{st[:, w, i].mean():9.0f}" for w in range(8)))
     sys.exit(0)
 NL = 2
 names = ["zero+windows+counts", "projection", "barrier"]

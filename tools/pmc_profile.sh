@@ -1,6 +1,7 @@
 #!/bin/bash
 # Hardware-counter passes for the fused kernel (run on the GPU box via gpurun).  One rocprofv3 run per
 # counter group, --kernel-trace only (no other trace domains), summaries under gpurun_out/pmc/.
+# The profiled command is the driver's: bench.py --steps 20 --warmup 5 (CPU legs and secondary workloads off).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmc
@@ -8,11 +9,9 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" --steps 16 --warmup 8 --cpu-seconds 0 ${BENCH_ARGS:-} > "$OUT/$name.log" 2>&1 || echo "pass $name failed"
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --cpu-seconds 0 --secondary none ${BENCH_ARGS:-} > "$OUT/$name.log" 2>&1 || echo "pass $name failed"
 }
 run sq    SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32
-#run tcp   TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum
-#run tcc   TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run rdsz  TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
