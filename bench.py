@@ -153,7 +153,7 @@ def run_dygformer(wk: DygformerWorkload, steps: int, warmup: int, F: int, rank: 
             if ev is not None:
                 ev[0].record(st)
                 wk.model._kernel_events = (ev[2], ev[3])      # recorded by the library right around the fused kernel's launch
-            s, d = wk.model.compute_src_dst_node_temporal_embeddings_many(srcs, dsts, ts)      # [2n, B, 172]
+            s, d = wk.model.compute_src_dst_node_temporal_embeddings_many(srcs, dsts, ts, pos_neg_halves=True)      # [2n, B, 172]
             if ev is not None:
                 wk.model._kernel_events = None
                 ev[1].record(st)

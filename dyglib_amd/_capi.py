@@ -106,7 +106,7 @@ SIGNATURES = {
     "dygnn_dygformer_workspace_bytes": (C.c_size_t, [C.POINTER(DygformerConfig), C.c_int64]),
     "dygnn_dygformer_workspace_bytes_for": (C.c_size_t, [C.POINTER(DygformerConfig), C.c_int64, C.c_int32]),
     "dygnn_dygformer_forward": (C.c_int, [C.POINTER(DygformerConfig), C.POINTER(DygformerWeights), C.c_void_p, C.POINTER(Csr),
-                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(DygformerTaps),
                                           C.c_int32, C.c_void_p]),
     "dygnn_tgat_workspace_bytes": (C.c_size_t, [C.POINTER(TgatConfig), C.c_int64]),

@@ -6,15 +6,15 @@ namespace dygnn {
 int pack_generic(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, float* packed, hipStream_t);
 int forward_generic(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, const float* packed, const dygnn_csr*,
                     const float* node_feat, const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times,
-                    int64_t B, int64_t G, float* out_src, float* out_dst, char* ws, const WorkspaceLayout&, const dygnn_dygformer_taps*,
-                    hipStream_t);
+                    int64_t B, int64_t G, int64_t pair_stride, float* out_src, float* out_dst, char* ws, const WorkspaceLayout&,
+                    const dygnn_dygformer_taps*, hipStream_t);
 // dygformer_fused3.hip
 bool fused3_supported(const Dims&);
 int pack_fused3(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, float* packed, hipStream_t);
 int forward_fused3(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, const float* packed, const dygnn_csr*,
                    const float* node_feat, const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times,
-                   int64_t B, int64_t G, float* out_src, float* out_dst, char* ws, const WorkspaceLayout&, const dygnn_dygformer_taps*,
-                   hipStream_t);
+                   int64_t B, int64_t G, int64_t pair_stride, float* out_src, float* out_dst, char* ws, const WorkspaceLayout&,
+                   const dygnn_dygformer_taps*, hipStream_t);
 
 static int check_weights(const Dims& d, const dygnn_dygformer_weights* w) {
     DYGNN_REQUIRE(w != nullptr, "weights is NULL");
@@ -154,9 +154,9 @@ extern "C" int dygnn_dygformer_pack(const dygnn_dygformer_config* cfg, const dyg
 
 extern "C" int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, const void* packed,
                                        const dygnn_csr* csr, const float* node_feat, const float* edge_feat, const int64_t* src,
-                                       const int64_t* dst, const double* times, int64_t batch, int64_t group_size, float* out_src,
-                                       float* out_dst, void* workspace, size_t workspace_bytes, const dygnn_dygformer_taps* taps, int32_t impl,
-                                       dygnn_stream_t stream) {
+                                       const int64_t* dst, const double* times, int64_t batch, int64_t group_size, int64_t pair_stride,
+                                       float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, const dygnn_dygformer_taps* taps,
+                                       int32_t impl, dygnn_stream_t stream) {
     if (int rc = check_config(cfg)) return rc;
     const Dims d = make_dims(*cfg);
     if (int rc = check_weights(d, w)) return rc;
@@ -164,6 +164,8 @@ extern "C" int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg, const 
     DYGNN_REQUIRE(batch >= 0, "forward: negative batch");
     DYGNN_REQUIRE(group_size >= 0, "forward: negative group_size");
     if (group_size == 0 || group_size > batch) group_size = batch;      // one group = the reference's single call
+    DYGNN_REQUIRE(pair_stride == 0 || (2 * pair_stride == batch && pair_stride % group_size == 0),
+                  "forward: pair_stride must be 0 or batch / 2, a whole number of groups (pairs i and i + pair_stride = the positive and negative call of one edge)");
     DYGNN_REQUIRE(packed && node_feat && edge_feat, "forward: null table / packed pointer");
     DYGNN_REQUIRE(batch == 0 || (src && dst && times && out_src && out_dst && workspace), "forward: null pointer");
     DYGNN_REQUIRE(impl == 0 || impl == 1 || impl == 3, "forward: impl must be 0 (auto), 1 (generic) or 3 (fused, token-owner layout)");
@@ -182,7 +184,7 @@ extern "C" int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg, const 
     }
     auto fn = forward_generic;
     if (impl == 3 || (impl == 0 && can_fuse3)) fn = forward_fused3;
-    return fn(d, pl, w, static_cast<const float*>(packed), csr, node_feat, edge_feat, src, dst, times, batch, group_size, out_src, out_dst,
+    return fn(d, pl, w, static_cast<const float*>(packed), csr, node_feat, edge_feat, src, dst, times, batch, group_size, pair_stride, out_src, out_dst,
               static_cast<char*>(workspace), wl, taps, as_stream(stream));
 }
 

@@ -176,6 +176,8 @@ struct Args {
     float* tap_enc; float* tap_layer[DYGNN_MAX_LAYERS];
     unsigned long long* stamps;
     int64_t B, G, num_nodes;
+    int64_t pair_stride;          // > 0 (two pairs per workgroup only): workgroup w holds pairs w and w + pair_stride — the positive and the
+                                  // negative call of one edge: where their (src, t) agree the src side is projected once
     int Fn, Fe, Ft, P, L, NL, Tmax;
     int nchunk[4];
     float qscale;
@@ -380,8 +382,9 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pi = wave / TPW, tt = wave % TPW;
     const int c = lane & 15, g = lane >> 4;
-    const int64_t b = (int64_t)blockIdx.x * NP + pi;
-    const bool pair_ok = b < a.B;
+    const bool paired = NP == 2 && a.pair_stride > 0;
+    const int64_t b = paired ? (int64_t)blockIdx.x + pi * a.pair_stride : (int64_t)blockIdx.x * NP + pi;
+    const bool pair_ok = paired ? blockIdx.x < a.pair_stride && b < a.B : b < a.B;
     const int ptid = tid - pi * PT;
 
     TDECL;
@@ -391,6 +394,22 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
     const int SsA = (Ss + 3) & ~3, SdA = (Sd + 3) & ~3, SA = SsA + SdA;
     const bool active = 16 * tt < T;             // wave-uniform: this token tile holds real tokens
     const int tokbase = pi * (16 * TPW);         // this pair's first K/V row
+    // f4 (caller-side fusion, train_link_prediction.py:166 / evaluate_models_utils.py:62-63): the second pair of the workgroup is the
+    // NEGATIVE call of the first pair's edge when it has the same source, the same time and the same padded source length.  Its token
+    // tiles that hold source tokens only then take the node / edge / time rows of the residual stream from the first pair's same tile
+    // instead of gathering and projecting them again (rows of one channel receive non-zero terms from that channel only, so the bits are
+    // those of a separate call); the co-occurrence rows and the destination side are its own.  Anything else: the plain path.
+    bool src_shared = false;
+    if (NP == 2) {
+        if (paired && pi == 1 && pair_ok) {
+            const int64_t b0 = blockIdx.x;
+            const CallDims cd0 = a.cd[b0 / a.G];
+            src_shared = a.src[b0] == a.src[b] && __double_as_longlong(a.times[b0]) == __double_as_longlong(a.times[b]) && cd0.S_s == Ss &&
+                         16 * (tt + 1) <= Ts;
+        }
+        src_shared = __builtin_amdgcn_readfirstlane((int)src_shared) != 0;
+    }
+    const bool donor = NP == 2 && paired && pi == 0 && 16 * (tt + 1) <= Ts;     // first-pair tiles a shared tile may copy from (checked by the taker)
 
     // ---- weights start moving at once: the first four stages of the layer stream into the ring, the first slab of
     // projection fragments into the K/V region behind the window arrays (all of it lands during the window phase)
@@ -485,6 +504,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
         // LDS only when pp moves on (once per ~11 chunks), so the gather address never waits for an LDS round trip
         struct Cursor { int pp, f, row; };
         int sstep = 0, next_slab = 1;
+        bool work = active && !src_shared;       // this wave gathers / multiplies in the current channel (shared source tiles: co-occurrence only)
         // fragments of the next step (all waves call this in lock-step); *fresh: a new slab was loaded for it
         auto slab_step = [&](bool& fresh) -> const float* {
             fresh = false;
@@ -517,7 +537,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
             constexpr int L0 = decltype(LOCAL0)::value;
             bool fresh;
             const float* fr = slab_step(fresh);
-            if (active) {
+            if (work) {
                 if (first || fresh) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) fa[PR][v] = lds4(fr + v * kFrag);
@@ -534,7 +554,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
         // gathered channel: bq[] holds the operands of the next DQ chunks
         auto prefill = [&](f4 (&bq)[DQ], Cursor& cu, const float* table, const int32_t* idx, int F) {
             cu = Cursor{0, 4 * g, row_of(idx, 0)};
-            if (active) {
+            if (work) {
 #pragma unroll
                 for (int u = 0; u < DQ; ++u) { bq[u] = gather(table, F, cu); step_gather(cu, idx, F); }
             }
@@ -546,7 +566,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                 for (int u = 0; u < DQ; ++u) {
                     if (kc0 + u < nchunk) {
                         const f4 bcur = bq[u];
-                        if (active) { bq[u] = gather(table, F, cu); step_gather(cu, idx, F); }   // chunk kc0+u+DQ (zeros beyond the patch)
+                        if (work) { bq[u] = gather(table, F, cu); step_gather(cu, idx, F); }   // chunk kc0+u+DQ (zeros beyond the patch)
                         mma_step(LOCAL0, u & 1, fa, kc0 + u == 0, kc0 + u + 1 < nchunk, bcur);
                     }
                 }
@@ -558,7 +578,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
         auto run_computed = [&](auto LOCAL0, int nchunk, auto bfn) {
             f4 br[DC];
             f4 fa[2][4];
-            if (active) {
+            if (work) {
 #pragma unroll
                 for (int u = 0; u < DC; ++u) br[u] = bfn();
             }
@@ -567,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                 for (int u = 0; u < DC; ++u) {
                     if (kc0 + u < nchunk) {
                         const f4 bcur = br[u];
-                        if (active) br[u] = bfn();
+                        if (work) br[u] = bfn();
                         mma_step(LOCAL0, u & 1, fa, kc0 + u == 0, kc0 + u + 1 < nchunk, bcur);
                     }
                 }
@@ -622,11 +642,30 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
         TACC(T_PTIME);
         run_gathered(std::integral_constant<int, 3>{}, bq, cu, a.nchunk[1], a.edge_feat, eids, a.Fe);
         TACC(T_PEDGE);
+        work = active;
         run_computed(std::integral_constant<int, 9>{}, a.nchunk[3], coocf);
         TACC(T_PCOOC);
     }
     TACC(T_PROJ);
     __syncthreads();     // everyone is done with the window arrays and the slab
+    if (NP == 2 && paired) {
+        // f4: source tiles of the second pair take rows 0 .. 149 (node, edge, time channels: tiles 0 .. 8 whole, tile 9 rows 144 .. 149) of the
+        // first pair's same tile through the (now free) K/V region; [donor tile tt][x tile i][lane] float4
+        f4* xch = reinterpret_cast<f4*>(lds);
+        if (donor) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) xch[(tt * 10 + i) * 64 + lane] = x[i];
+        }
+        __syncthreads();
+        if (src_shared) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) x[i] = xch[(tt * 10 + i) * 64 + lane];
+            const f4 v = xch[(tt * 10 + 9) * 64 + lane];       // tile 9 = rows 144 + 4 g + r: time channel up to row 149
+            if (g == 0) x[9] = v;
+            else if (g == 1) { x[9].x = v.x; x[9].y = v.y; }
+        }
+        __syncthreads();
+    }
     // K, V and the slack behind them: rows of absent tokens are read as MFMA operands and must be finite
     for (int i = tid; i < kLdsRing / 4; i += 512) reinterpret_cast<f4*>(lds)[i] = zero4();
     tap_store<TPW>(x, a.tap_enc, b, a.Tmax, T, tt, c, g);
@@ -892,7 +931,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                 if (kc & 1) { acc1 = mfma(fa[kc].x, bm.x, acc1); acc1 = mfma(fa[kc].y, bm.y, acc1); acc1 = mfma(fa[kc].z, bm.z, acc1); acc1 = mfma(fa[kc].w, bm.w, acc1); }
                 else { acc0 = mfma(fa[kc].x, bm.x, acc0); acc0 = mfma(fa[kc].y, bm.y, acc0); acc0 = mfma(fa[kc].z, bm.z, acc0); acc0 = mfma(fa[kc].w, bm.w, acc0); }
             }
-            const int64_t bo_ = (int64_t)blockIdx.x * NP + (c >> 1);
+            const int64_t bo_ = paired ? (int64_t)blockIdx.x + (c >> 1) * a.pair_stride : (int64_t)blockIdx.x * NP + (c >> 1);
             if (c < 2 * NP && bo_ < a.B && j0 < a.Fn)
                 *reinterpret_cast<f4*>(((c & 1) ? a.out_dst : a.out_src) + bo_ * a.Fn + j0) = acc0 + acc1;
         }
@@ -1128,7 +1167,7 @@ int pack_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_wei
 
 int forward_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, const float* packed,
                    const dygnn_csr* csr, const float* node_feat, const float* edge_feat, const int64_t* src,
-                   const int64_t* dst, const double* times, int64_t B, int64_t G, float* out_src, float* out_dst, char* ws,
+                   const int64_t* dst, const double* times, int64_t B, int64_t G, int64_t pair_stride, float* out_src, float* out_dst, char* ws,
                    const WorkspaceLayout& wl, const dygnn_dygformer_taps* taps, hipStream_t s) {
     using namespace v3;
     if (!supported(d)) { set_error("fused kernel: unsupported shape"); return DYGNN_E_UNSUPPORTED; }
@@ -1164,7 +1203,8 @@ int forward_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_
     DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     if (taps && taps->ev_kernel_start) DYGNN_HIP(hipEventRecord(static_cast<hipEvent_t>(taps->ev_kernel_start), s));
-    if (f.np == 2) hipLaunchKernelGGL(k_dygformer_fused3<4>, dim3((unsigned)((B + 1) / 2)), dim3(512), kLdsBytes, s, a);
+    a.pair_stride = (f.np == 2 && pair_stride > 0) ? pair_stride : 0;      // one pair per workgroup (128 tokens): nothing to share inside a workgroup
+    if (f.np == 2) hipLaunchKernelGGL(k_dygformer_fused3<4>, dim3((unsigned)(a.pair_stride ? a.pair_stride : (B + 1) / 2)), dim3(512), kLdsBytes, s, a);
     else hipLaunchKernelGGL(k_dygformer_fused3<8>, dim3((unsigned)B), dim3(512), kLdsBytes, s, a);
     DYGNN_LAUNCH_CHECK();
     if (taps && taps->ev_kernel_stop) DYGNN_HIP(hipEventRecord(static_cast<hipEvent_t>(taps->ev_kernel_stop), s));

@@ -436,7 +436,7 @@ int window_lengths_device(const Dims& d, const dygnn_csr* csr, const int64_t* sr
 
 int forward_generic(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, const float* packed,
                     const dygnn_csr* csr, const float* node_feat, const float* edge_feat, const int64_t* src,
-                    const int64_t* dst, const double* times, int64_t B, int64_t G, float* out_src, float* out_dst, char* ws,
+                    const int64_t* dst, const double* times, int64_t B, int64_t G, int64_t /*pair_stride: a fused-kernel launch option, results are the same*/, float* out_src, float* out_dst, char* ws,
                     const WorkspaceLayout& wl, const dygnn_dygformer_taps* taps, hipStream_t s) {
     DYGNN_REQUIRE(d.Tmax <= 128, "generic path supports at most 128 tokens per pair (2*ceil(L/P) = %d)", d.Tmax);
     if (int rc = window_lengths_device(d, csr, src, dst, times, B, G, ws, wl, s)) return rc;

@@ -162,7 +162,7 @@ class DyGFormer(nn.Module):
             self.neighbor_sampler.reset_random_state()
 
     def compute_src_dst_node_temporal_embeddings(self, src_node_ids, dst_node_ids, node_interact_times,
-                                                 _taps: Optional[dict] = None, _group_size: int = 0
+                                                 _taps: Optional[dict] = None, _group_size: int = 0, _pair_stride: int = 0
                                                  ) -> Tuple[torch.Tensor, torch.Tensor]:
         """models/DyGFormer.py:68-194.  ndarray (or already-resident device tensor) [B] int64, [B] int64,
         [B] float64 -> two float32 tensors [B, node_feat_dim] on the model's device."""
@@ -198,17 +198,20 @@ class DyGFormer(nn.Module):
         rc = self._lib.dygnn_dygformer_forward(
             C.byref(self._cfg), C.byref(weights), packed.data_ptr(), csr,
             self.node_raw_features.data_ptr(), self.edge_raw_features.data_ptr(),
-            src.data_ptr(), dst.data_ptr(), tms.data_ptr(), B, int(_group_size), out_src.data_ptr(), out_dst.data_ptr(),
+            src.data_ptr(), dst.data_ptr(), tms.data_ptr(), B, int(_group_size), int(_pair_stride), out_src.data_ptr(), out_dst.data_ptr(),
             ws.data_ptr(), ws.numel(), C.byref(taps_struct) if taps_struct is not None else None,
             int(self.impl), _capi.current_stream_ptr())
         _capi.check(rc)
         return out_src, out_dst
 
-    def compute_src_dst_node_temporal_embeddings_many(self, src_node_ids, dst_node_ids, node_interact_times):
+    def compute_src_dst_node_temporal_embeddings_many(self, src_node_ids, dst_node_ids, node_interact_times, pos_neg_halves: bool = False):
         """Several independent reference calls in ONE launch: inputs are [N, B] (N calls of B pairs each; e.g. the
         positive and the negative call of a step, or N evaluation batches).  Row i of the result equals
         compute_src_dst_node_temporal_embeddings(src[i], dst[i], t[i]) bit for bit (every call keeps its own
         padded lengths), but the N*B pairs form one grid, which keeps all 256 CUs busy instead of B of them.
+        pos_neg_halves=True (N even): calls N/2 .. N-1 are the NEGATIVE calls of calls 0 .. N/2-1 — same sources and times, other
+        destinations (train_link_prediction.py:165-166) — so the kernel handles the two pairs of an edge together and gathers /
+        projects the shared source side once; the rows stay bit-identical.
         Returns two float32 tensors [N, B, node_feat_dim]."""
         dev = self._device()
         self._validate_ids(src_node_ids, dst_node_ids)
@@ -231,7 +234,10 @@ class DyGFormer(nn.Module):
                 return a.reshape(N, B, -1), b.reshape(N, B, -1)
             outs = [self.compute_src_dst_node_temporal_embeddings(src[i], dst[i], tms[i]) for i in range(N)]
             return torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs])
-        a, b = self.compute_src_dst_node_temporal_embeddings(src.reshape(-1), dst.reshape(-1), tms.reshape(-1), _group_size=B)
+        if pos_neg_halves and N % 2 != 0:
+            raise AssertionError("pos_neg_halves needs an even number of calls: [positive calls ; negative calls]")
+        a, b = self.compute_src_dst_node_temporal_embeddings(src.reshape(-1), dst.reshape(-1), tms.reshape(-1), _group_size=B,
+                                                             _pair_stride=(N // 2) * B if pos_neg_halves else 0)
         return a.reshape(N, B, -1), b.reshape(N, B, -1)
 
     def _dropout_and_seed(self):

@@ -85,7 +85,7 @@ def evaluate_model_link_prediction(model_name: str, model: nn.Module, neighbor_s
             src = np.stack([g[0] for g in groups_pos] + [g[0] for g in groups_neg])
             dst = np.stack([g[1] for g in groups_pos] + [g[1] for g in groups_neg])
             tms = np.stack([g[2] for g in groups_pos] + [g[2] for g in groups_neg])
-            a, b = backbone.compute_src_dst_node_temporal_embeddings_many(src, dst, tms)
+            a, b = backbone.compute_src_dst_node_temporal_embeddings_many(src, dst, tms, pos_neg_halves=True)      # [positives ; negatives]
             prob = merge.link_probabilities(a.reshape(2 * n * B, -1), b.reshape(2 * n * B, -1)).reshape(2, n, B)
         elif model_name == "TGAT" and neighbor_sampler.sample_neighbor_strategy == "recent":
             # rows do not depend on the batch they are in (fixed k, stateless sampling): the n batches are one call on n*B edges

@@ -172,6 +172,10 @@ size_t dygnn_dygformer_workspace_bytes_for(const dygnn_dygformer_config* cfg_hos
  * the result of every group is bit-identical to a separate reference call on that group, so several
  * reference calls (e.g. the positive and the negative call of a step, evaluate_models_utils.py:126-136, or
  * several evaluation batches) run as ONE grid that keeps all 256 CUs busy.  G = 0 or G >= batch: one group.
+ * pair_stride (caller-side fusion): 0, or batch / 2 when the batch is [positive calls ; negative calls] of the same
+ * edges — pair i + pair_stride has the source and time of pair i (train_link_prediction.py:165-166, evaluate_models_utils.py:62-63).
+ * The fused kernel then puts both pairs of an edge in one workgroup and gathers / projects the shared source side once; every row
+ * is still bit-identical to the separate reference calls, and pairs whose (src, t) differ simply take the plain path.
  * impl: 0 = auto (the fused MFMA kernel when the shape is supported, else generic),
  *       1 = generic multi-kernel path (any shape),
  *       3 = fused kernel, token-owner layout (<= 128 tokens per pair; error if unsupported);
@@ -184,7 +188,7 @@ int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg_host, const dygnn_
                             const void* packed, const dygnn_csr* csr_host,
                             const float* node_feat, const float* edge_feat,
                             const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
-                            int64_t group_size, float* out_src, float* out_dst,
+                            int64_t group_size, int64_t pair_stride, float* out_src, float* out_dst,
                             void* workspace, size_t workspace_bytes,
                             const dygnn_dygformer_taps* taps_host, int32_t impl, dygnn_stream_t stream);
 

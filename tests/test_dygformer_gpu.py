@@ -143,6 +143,37 @@ def test_wikipedia_scale_batch_against_oracle():
             close(gd.cpu().numpy(), od.numpy(), f"impl {impl} dst")
 
 
+@pytest.mark.parametrize("name", ["bip_p2_l64", "hub_p4_l48", "gen_p1_l32", "bip_p8_l512"])
+def test_positive_and_negative_call_in_one_workgroup_match_separate_calls(name):
+    """SURVEY §8f-4 for DyGFormer: [positive calls ; negative calls] with pos_neg_halves=True puts both pairs of an edge in one workgroup
+    and projects the shared source side once.  Every row must equal the separate reference calls BIT FOR BIT — for full source tiles
+    (the shared path), for source lengths that are not a multiple of 16 tokens (plain path), for a 128-token shape (one pair per
+    workgroup: nothing shared) and for "negatives" whose source or time differs (plain path, per pair)."""
+    c = gc.build_case(name)
+    model, _ = build_model(c)
+    d = c["data"]
+    E = d.num_interactions
+    B = min(24, len(c["src"]))
+    rows = [np.arange(E - 2 * B, E - B), np.arange(E - B, E)]          # two positive calls (long histories)
+    rs = np.random.RandomState(5)
+    src = np.stack([d.src_node_ids[r] for r in rows] * 2)                # negatives: the same sources ...
+    t = np.stack([d.node_interact_times[r] for r in rows] * 2)           # ... and times ...
+    neg = [rs.choice(np.unique(d.dst_node_ids), size=B) for _ in rows]   # ... other destinations
+    dst = np.stack([d.dst_node_ids[r] for r in rows] + neg)
+    # a few "negatives" that are NOT the negative of their partner: another source / another time
+    src[2, 1], t[3, 2] = src[2, 0], t[3, 0] - 1.0
+    model.impl = 3
+    with torch.no_grad():
+        ps, pd = model.compute_src_dst_node_temporal_embeddings_many(src, dst, t, pos_neg_halves=True)
+        qs, qd = model.compute_src_dst_node_temporal_embeddings_many(src, dst, t)
+        for i in range(4):
+            s1, d1 = model.compute_src_dst_node_temporal_embeddings(src[i], dst[i], t[i])
+            assert torch.equal(ps[i], s1) and torch.equal(pd[i], d1), (name, i)
+            assert torch.equal(qs[i], s1) and torch.equal(qd[i], d1), (name, i)
+    with pytest.raises(AssertionError), torch.no_grad():
+        model.compute_src_dst_node_temporal_embeddings_many(src[:3], dst[:3], t[:3], pos_neg_halves=True)
+
+
 def test_many_calls_in_one_launch_match_separate_calls():
     """group_size: several independent reference calls as ONE grid.  Every group keeps its own padded lengths, so the
     result must equal the separate calls BIT FOR BIT, including groups whose S_src/S_dst differ."""

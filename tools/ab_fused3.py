@@ -19,6 +19,7 @@ names = [("" if a == "default" else a) for a in sys.argv[1:]] or ["", "f3base"]
 rounds = int(os.environ.get("AB_ROUNDS", "9"))
 F = int(os.environ.get("AB_STEPS", "32"))
 workload = os.environ.get("AB_WORKLOAD", "wikipedia")
+PAIRED = os.environ.get("AB_PAIRED", "1") != "0"      # positive and negative pair of an edge in one workgroup (f4)
 dev = torch.device("cuda", 0)
 wk = bench.DygformerWorkload(workload, dev)
 arms = []
@@ -37,14 +38,14 @@ srcs, dsts, ts = torch.cat([src, src]), torch.cat([wk.dst_all[idx], wk.neg_all[i
 outs, times = [], [[] for _ in arms]
 with torch.no_grad():
     for m in arms:
-        outs.append(m.compute_src_dst_node_temporal_embeddings_many(srcs, dsts, ts))
+        outs.append(m.compute_src_dst_node_temporal_embeddings_many(srcs, dsts, ts, pos_neg_halves=PAIRED))
     torch.cuda.synchronize()
     for r in range(rounds):
         for i, m in enumerate(arms):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(2):
-                m.compute_src_dst_node_temporal_embeddings_many(srcs, dsts, ts)
+                m.compute_src_dst_node_temporal_embeddings_many(srcs, dsts, ts, pos_neg_halves=PAIRED)
             e1.record()
             torch.cuda.synchronize()
             times[i].append(e0.elapsed_time(e1) / 2)
