@@ -109,6 +109,73 @@ __global__ __launch_bounds__(256) void k_merge_sigmoid_mfma(const float* __restr
     if (g == 0 && mv) out[m] = 1.0f / (1.0f + expf(-(z + b2[0])));
 }
 
+
+// The same head for a few hundred rows (one evaluation step: 400 .. 800): one workgroup = 16 rows, its 4 waves split the hidden units
+// (wave w: three 16-wide tiles from 48 w), so the rows' features and fc1 are read once per 16 rows instead of once per row (the
+// one-workgroup-per-row kernel moves hidden x 2 dim x 4 B = 237 KB of fc1 through L2 for EVERY row) and 50 workgroups run side by side
+// where the wave-per-16-rows form above would run 13.  Operands come straight from global memory / L2, four k-steps ahead in registers.
+__global__ __launch_bounds__(256) void k_merge_sigmoid_mid(const float* __restrict__ a, const float* __restrict__ b, int64_t n_rows, int dim,
+                                                             int hidden, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             const float* __restrict__ w2, const float* __restrict__ b2,
+                                                             float* __restrict__ out) {
+    __shared__ float zpart[4][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t m = (int64_t)blockIdx.x * 16 + c;
+    const bool mv = m < n_rows;
+    const int K = 2 * dim, nsteps = (K + 15) >> 4;
+    constexpr int PF = 4;
+    const int n0 = 48 * wave;
+    auto load_b = [&](int st) -> mf4 {
+        const int kk = 16 * st + 4 * g;
+        if (!(mv && kk < K)) return mf4{0.f, 0.f, 0.f, 0.f};
+        return kk < dim ? *reinterpret_cast<const mf4*>(a + m * dim + kk) : *reinterpret_cast<const mf4*>(b + m * dim + (kk - dim));
+    };
+    auto load_a = [&](int st, int i) -> mf4 {
+        const int kk = 16 * st + 4 * g, n = n0 + 16 * i + c;
+        return (n < hidden && kk < K) ? *reinterpret_cast<const mf4*>(w1 + (size_t)n * K + kk) : mf4{0.f, 0.f, 0.f, 0.f};
+    };
+    mf4 acc[3] = {mf4{0.f, 0.f, 0.f, 0.f}, mf4{0.f, 0.f, 0.f, 0.f}, mf4{0.f, 0.f, 0.f, 0.f}};
+    mf4 bq[PF], aq[PF][3];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        bq[u] = load_b(u);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) aq[u][i] = load_a(u, i);
+    }
+    for (int st0 = 0; st0 < nsteps; st0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (st0 + u < nsteps) {
+                const mf4 bf = bq[u];
+                mf4 af[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) af[i] = aq[u][i];
+                bq[u] = load_b(st0 + u + PF);                  // beyond K: zeros, no access
+#pragma unroll
+                for (int i = 0; i < 3; ++i) aq[u][i] = load_a(st0 + u + PF, i);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[t], acc[i], 0, 0, 0);
+            }
+        }
+    }
+    float z = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + 16 * i + 4 * g + r;
+            if (n < hidden) z = fmaf(fmaxf(acc[i][r] + b1[n], 0.f), w2[n], z);
+        }
+    z += __shfl_xor(z, 16, 64);
+    z += __shfl_xor(z, 32, 64);
+    if (g == 0) zpart[wave][c] = z;
+    __syncthreads();
+    if (wave == 0 && g == 0 && mv) out[m] = 1.0f / (1.0f + expf(-(((zpart[0][c] + zpart[1][c]) + (zpart[2][c] + zpart[3][c])) + b2[0])));
+}
+
 }  // namespace dygnn
 
 using namespace dygnn;
@@ -196,6 +263,12 @@ extern "C" int dygnn_merge_layer_sigmoid(const float* a, const float* b, int64_t
     if (n == 0) return DYGNN_OK;
     if (dim % 4 == 0 && n >= 2048) {        // few rows: the one-workgroup-per-row kernel below has the shorter critical path
         hipLaunchKernelGGL(k_merge_sigmoid_mfma, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, as_stream(stream), a, b, n, dim, hidden,
+                           fc1_w, fc1_b, fc2_w, fc2_b, out);
+        DYGNN_LAUNCH_CHECK();
+        return DYGNN_OK;
+    }
+    if (dim % 4 == 0 && hidden <= 192 && n >= 64) {     // an evaluation step's worth of rows
+        hipLaunchKernelGGL(k_merge_sigmoid_mid, dim3((unsigned)ceil_div(n, 16)), dim3(256), 0, as_stream(stream), a, b, n, dim, hidden,
                            fc1_w, fc1_b, fc2_w, fc2_b, out);
         DYGNN_LAUNCH_CHECK();
         return DYGNN_OK;

@@ -22,7 +22,8 @@
 #include "dygformer_layout.h"
 
 // Build-time switch (tools/ab_fused3.py builds the other arm with -DF3_KSKIP=0 to A/B it in one process):
-//   F3_KSKIP     the K = 200 products (QKV, FFN W1) spend 2 instead of 4 MFMAs on their last k-chunk (192..207: only 8 real k)
+//   F3_KSKIP     the K = 200 products (QKV, FFN W1) spend 2 instead of 4 MFMAs on their last k-chunk (192..207: only 8 real k), the head-dim
+//                contractions (Q K^T, out-projection) 1 instead of 4 on theirs (96..111: only 4 real k)
 // Measured and NOT kept (round 2, profiles/r02_fused3_ab.md): a software-pipelined FFN (stream order W1(p+1) before W2(p), GELU of step p
 // issued inside the W1(p+1) block — in chunks between MFMA groups, or whole before / after the block's MFMAs with the two waves of a SIMD at
 // opposite ends): 1.3-1.6 % SLOWER in every arrangement, the two waves of a SIMD already run the block one after the other (the older or
@@ -30,6 +31,9 @@
 // stage barriers every 13 instead of 26 fragments in the FFN with the next group's fragments read before the barrier: slower (twice the barriers).
 #ifndef F3_KSKIP
 #define F3_KSKIP 1
+#endif
+#ifndef F3_DQ
+#define F3_DQ 8
 #endif
 
 namespace dygnn {
@@ -85,6 +89,21 @@ __device__ __forceinline__ void kpack(const f4 v, float& b0, float& b1) {
     const auto r1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, vz), __builtin_bit_cast(unsigned, vw), false, false);
     b0 = __builtin_bit_cast(float, r0[0]);
     b1 = __builtin_bit_cast(float, r1[0]);
+}
+// v = rows 96 + 4 g + r of a head-dim tile: only rows 96 .. 99 (lane group 0) are real (head dim 100).  Returns the B operand of ONE
+// MFMA that carries all four: lane group g holds row 96 + g (permlane16_swap: 16-lane rows 1, 3 of the first operand <-> rows 0, 2 of the
+// second; then permlane32_swap as in kpack).  The A fragments of that k-chunk are packed to match (FragDesc.kmode 2: k = 96 + g).
+__device__ __forceinline__ float kpack4(const f4 v) {
+    const float vx = v.x, vy = v.y, vz = v.z, vw = v.w;
+    const auto t1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, vx), __builtin_bit_cast(unsigned, vy), false, false);
+    const auto t2 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, vz), __builtin_bit_cast(unsigned, vw), false, false);
+    const auto r = __builtin_amdgcn_permlane32_swap(t1[0], t2[0], false, false);
+    return __builtin_bit_cast(float, r[0]);
+}
+template <int N>
+__device__ __forceinline__ void mma_group1(f4* acc, const f4* a, const float b0) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) acc[u] = mfma(a[u].x, b0, acc[u]);
 }
 __device__ __forceinline__ f4 ldg4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ f4 lds4(const float* p) { return *reinterpret_cast<const f4*>(p); }
@@ -499,7 +518,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
         const bool tv = tok < T;
         const int pos0 = tv ? (tok < Ts ? tok * a.P : SsA + (tok - Ts) * a.P) : 0;
         const int P = a.P;
-        constexpr int DQ = 8;
+        constexpr int DQ = F3_DQ;          // gathered chunks in flight per lane (measured: profiles/r02_fused3_ab.md)
         // (pp, f) = patch position and feature of this lane's k; row = the table row of that position, re-read from
         // LDS only when pp moves on (once per ~11 chunks), so the gather address never waits for an LDS round trip
         struct Cursor { int pp, f, row; };
@@ -737,6 +756,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                 f4 sa[TPW];
 #pragma unroll
                 for (int kt = 0; kt < TPW; ++kt) sa[kt] = zero4();
+                const float q6 = F3_KSKIP ? kpack4(qa[6]) : 0.f;       // rows 96 .. 99 of Q^T for the one-MFMA last d-chunk
                 // S^T[key][query] = sum_d K[key][d] * Q^T[d][query]; key tiles in chunks of 4
 #pragma unroll
                 for (int kh = 0; kh < TPW / 4; ++kh) {
@@ -746,12 +766,15 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                     for (int kt = 0; kt < 4; ++kt) kf[0][kt] = lds4(kbase + 16 * kt * kKV);
 #pragma unroll
                     for (int j = 0; j < 7; ++j) {
-                        if (j + 1 < 7) {
+                        if (j + 1 < 6 || (!F3_KSKIP && j + 1 < 7)) {
 #pragma unroll
                             for (int kt = 0; kt < 4; ++kt) kf[(j + 1) & 1][kt] = lds4(kbase + 16 * kt * kKV + 16 * (j + 1));
+                        } else if (j + 1 == 6) {     // d = 96 .. 99 in ONE MFMA: lane group g reads K[key][96 + g] (kbase points at column 4 g)
+#pragma unroll
+                            for (int kt = 0; kt < 4; ++kt) kf[0][kt].x = kbase[16 * kt * kKV + 96 - 3 * g];
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        mma_group<4>(&sa[4 * kh], kf[j & 1], qa[j]);
+                        if (F3_KSKIP && j == 6) mma_group1<4>(&sa[4 * kh], kf[0], q6); else mma_group<4>(&sa[4 * kh], kf[j & 1], qa[j]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -807,9 +830,11 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
             ws.fit(13);
             {
                 f4 fs[2][4];
+                float o6 = 0.f;              // rows 96 .. 99 of O^T for the one-MFMA last d-chunk
                 if (active) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) fs[0][v] = lds4(ringl + (ws.pos + v) * kFrag);
+                    if (F3_KSKIP) o6 = kpack4(oa[6]);
                 }
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {
@@ -829,7 +854,8 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                                 for (int v = 0; v < 4; ++v) fs[(gi + 1) & 1][v] = lds4(ringl + (pnext + v) * kFrag);
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                            if (n == 4) mma_group<4>(&x[i0], fs[gi & 1], oa[j]); else mma_group<3>(&x[i0], fs[gi & 1], oa[j]);
+                            if (F3_KSKIP && j == 6) { if (n == 4) mma_group1<4>(&x[i0], fs[gi & 1], o6); else mma_group1<3>(&x[i0], fs[gi & 1], o6); }
+                            else if (n == 4) mma_group<4>(&x[i0], fs[gi & 1], oa[j]); else mma_group<3>(&x[i0], fs[gi & 1], oa[j]);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -950,6 +976,7 @@ struct FragDesc {
     int r0, rmax;         // element (c,g,t): row = r0 + c, valid iff 0 <= row < rmax
     int c0, cmax;         //                  col = c0 + 4g + t, valid iff col < cmax
     int kmode;            // 1: last chunk of a K = 200 product, 8 real k in two MFMAs: t < 2: col = c0 + {0,4,1,5}[g] + 2t, t >= 2: zero (mma_group2)
+                          // 2: last chunk of a head-dim (100) contraction, 4 real k in one MFMA: t = 0: col = c0 + g, t >= 1: zero (mma_group1)
 };
 
 __global__ void k_pack_stream(const FragDesc* __restrict__ desc, int64_t nfrag, float* __restrict__ dst) {
@@ -961,6 +988,7 @@ __global__ void k_pack_stream(const FragDesc* __restrict__ desc, int64_t nfrag, 
     const int row = d.r0 + c;
     int col = d.c0 + 4 * g + t;
     if (d.kmode == 1) col = t < 2 ? d.c0 + (g & 1) * 4 + (g >> 1) + 2 * t : d.cmax;
+    if (d.kmode == 2) col = t == 0 ? d.c0 + g : d.cmax;
     float v = 0.f;
     if (d.src != nullptr) {
         if (d.ld < 0) { const int e = (int)(idx & 255); if (e < d.rmax) v = d.src[d.c0 + e]; }
@@ -1007,7 +1035,7 @@ static void build_stream(const Dims& d, const dygnn_dygformer_weights* w, Stream
             }
             sb.fit(13);
             for (int j = 0; j < 7; ++j) {                    // out-projection: [d-chunk j][n-tile i], columns of head h
-                for (int i = 0; i < kNT; ++i) sb.put(L.out_proj_weight, kD, 16 * i, kD, kHD * h + 16 * j, kHD * (h + 1));
+                for (int i = 0; i < kNT; ++i) sb.put(L.out_proj_weight, kD, 16 * i, kD, kHD * h + 16 * j, kHD * (h + 1), (F3_KSKIP && j == 6) ? 2 : 0);
                 if (j + 1 < 7) sb.fit(13);
             }
         }

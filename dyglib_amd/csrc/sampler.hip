@@ -94,6 +94,86 @@ __global__ __launch_bounds__(256) void k_sample_recent(CsrView g, const int64_t*
     }
 }
 
+// ---- four queries per wave (large batches) ----------------------------------------------------------------------------------
+// One wave per query leaves a CU with 32 queries in flight, each a chain of two or three dependent memory round trips: the kernel is
+// bound by that latency, not by bytes.  With 16 lanes per query a wave carries FOUR searches (the rows of a 16-ary search are still one
+// 128-byte line per probe step), so 128 queries are in flight per CU; the sub-group's ballot bits are cut out of the wave's 64-bit
+// ballot.  A search step divides the range by 16 instead of 64 (one more round trip on rows beyond 1024 entries), which the four-fold
+// overlap more than pays for once the batch is large enough to fill the chip (dispatch: n >= 16384).
+constexpr int kSub = 16;
+
+// first index p in [lo, hi) with ts[p] >= t, or hi, for the query of this lane's 16-lane sub-group.  All 64 lanes must call; `on`
+// = the sub-group has a query (inactive sub-groups pass lo == hi).
+__device__ __forceinline__ int64_t sub_lower_bound(const double* __restrict__ ts, int64_t lo, int64_t hi, double t, int sl, int sg) {
+    while (__any(hi - lo > kSub)) {
+        const bool wide = hi - lo > kSub;                                  // uniform inside a sub-group
+        const int64_t step = wide ? (hi - lo + kSub - 1) / kSub : 1;
+        const int64_t p = lo + (int64_t)sl * step;
+        const bool pred = wide && (p < hi) && (ts[p] < t);
+        const int c = __popc((unsigned)((__ballot(pred) >> (kSub * sg)) & 0xFFFFull));   // rows ascend => true exactly for sub-lanes < c
+        if (wide) {
+            if (c == 0) hi = lo;                                           // everything is >= t: the answer is lo
+            else {
+                const int64_t nlo = lo + (int64_t)(c - 1) * step + 1, nhi = lo + (int64_t)c * step;
+                hi = nhi < hi ? nhi : hi;
+                lo = nlo;
+            }
+        }
+    }
+    const int64_t p = lo + sl;
+    const bool pred = (p < hi) && (ts[p] < t);
+    return lo + __popc((unsigned)((__ballot(pred) >> (kSub * sg)) & 0xFFFFull));
+}
+
+__global__ __launch_bounds__(256) void k_sample_recent_sub(CsrView g, const int64_t* __restrict__ nodes, const double* __restrict__ times, int64_t n,
+                                                             int32_t k, int64_t* __restrict__ out_nbr, int64_t* __restrict__ out_eid,
+                                                             float* __restrict__ out_ts) {
+    const int lane = threadIdx.x & 63, sg = lane / kSub, sl = lane % kSub;
+    const int64_t q = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (kWave / kSub) + sg;
+    const bool on = q < n;
+    int64_t lo = 0, hi = 0;
+    double t = 0.0;
+    if (on) { query_row(g, nodes[q], lo, hi); t = times[q]; }
+    const int64_t i = sub_lower_bound(g.ts, lo, hi, t, sl, sg);
+    if (!on) return;
+    const int64_t len = i - lo;
+    const int32_t m = (int32_t)(len < k ? len : k);     // utils/utils.py:202-204
+    const int32_t pad = k - m;                          // right-aligned, utils/utils.py:207-209
+    int64_t* on_ = out_nbr + q * k;
+    int64_t* oe = out_eid + q * k;
+    float* ot = out_ts + q * k;
+    for (int32_t j = sl; j < k; j += kSub) {
+        if (j < pad) {
+            on_[j] = 0; oe[j] = 0; ot[j] = 0.0f;
+        } else {
+            const int64_t p = i - m + (j - pad);
+            on_[j] = g.nbr[p]; oe[j] = g.eid[p]; ot[j] = (float)g.ts[p];   // f64 -> f32 on store, utils.py:167
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_find_before_sub(CsrView g, const int64_t* __restrict__ nodes, const double* __restrict__ times, int64_t n,
+                                                           int32_t clampL, int32_t* __restrict__ hist_len, int64_t* __restrict__ end_pos,
+                                                           int32_t* __restrict__ max_window) {
+    const int lane = threadIdx.x & 63, sg = lane / kSub, sl = lane % kSub;
+    const int64_t q = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (kWave / kSub) + sg;
+    const bool on = q < n;
+    int64_t lo = 0, hi = 0;
+    double t = 0.0;
+    if (on) { query_row(g, nodes[q], lo, hi); t = times[q]; }
+    const int64_t row_lo = lo;
+    const int64_t i = sub_lower_bound(g.ts, lo, hi, t, sl, sg);
+    if (on && sl == 0) {
+        const int32_t len = (int32_t)(i - row_lo);
+        if (hist_len) hist_len[q] = len;
+        if (end_pos) end_pos[q] = i;
+        if (max_window) {
+            const int32_t v = len < clampL ? len : clampL;
+            if (v > __atomic_load_n(max_window, __ATOMIC_RELAXED)) atomicMax(max_window, v);
+        }
+    }
+}
+
 // gather of host-drawn samples (utils/utils.py:192-199): one thread per output slot
 __global__ __launch_bounds__(256) void k_gather_selected(CsrView g, const int64_t* __restrict__ nodes, const int32_t* __restrict__ sel,
                                                            int64_t total, int32_t k, int64_t* __restrict__ out_nbr,
@@ -145,6 +225,7 @@ static int check_csr(const dygnn_csr* c) {
     return DYGNN_OK;
 }
 
+constexpr int64_t kSubMinQueries = 16384;     // below: one wave per query (shortest chain); at and above: four queries per wave
 static CsrView view(const dygnn_csr* c) { return CsrView{c->indptr, c->nbr, c->eid, c->ts, c->num_nodes}; }
 
 }  // namespace dygnn
@@ -157,6 +238,10 @@ extern "C" int dygnn_find_neighbors_before(const dygnn_csr* csr, const int64_t* 
     DYGNN_REQUIRE(n >= 0 && (n == 0 || (nodes && times)), "find_neighbors_before: bad arguments");
     if (n == 0) return DYGNN_OK;
     const int wpb = 4;
+    if (n >= kSubMinQueries)
+        hipLaunchKernelGGL(k_find_before_sub, dim3((unsigned)ceil_div(n, wpb * (kWave / kSub))), dim3(wpb * kWave), 0, as_stream(stream), view(csr),
+                           nodes, times, n, INT32_MAX, hist_len, end_pos, (int32_t*)nullptr);
+    else
     hipLaunchKernelGGL(k_find_before, dim3((unsigned)ceil_div(n, wpb)), dim3(wpb * kWave), 0, as_stream(stream), view(csr),
                        nodes, times, n, INT32_MAX, hist_len, end_pos, (int32_t*)nullptr);
     DYGNN_LAUNCH_CHECK();
@@ -171,6 +256,10 @@ extern "C" int dygnn_sample_recent(const dygnn_csr* csr, const int64_t* nodes, c
     DYGNN_REQUIRE(n >= 0 && (n == 0 || (nodes && times && out_nbr && out_eid && out_ts)), "sample_recent: bad arguments");
     if (n == 0) return DYGNN_OK;
     const int wpb = 4;
+    if (n >= kSubMinQueries)
+        hipLaunchKernelGGL(k_sample_recent_sub, dim3((unsigned)ceil_div(n, wpb * (kWave / kSub))), dim3(wpb * kWave), 0, as_stream(stream), view(csr),
+                           nodes, times, n, k, out_nbr, out_eid, out_ts);
+    else
     hipLaunchKernelGGL(k_sample_recent, dim3((unsigned)ceil_div(n, wpb)), dim3(wpb * kWave), 0, as_stream(stream), view(csr),
                        nodes, times, n, k, out_nbr, out_eid, out_ts);
     DYGNN_LAUNCH_CHECK();
@@ -200,6 +289,10 @@ extern "C" int dygnn_window_lengths(const dygnn_csr* csr, const int64_t* nodes, 
     DYGNN_HIP(hipMemsetAsync(max_window, 0, sizeof(int32_t), as_stream(stream)));
     if (n == 0) return DYGNN_OK;
     const int wpb = 4;
+    if (n >= kSubMinQueries)
+        hipLaunchKernelGGL(k_find_before_sub, dim3((unsigned)ceil_div(n, wpb * (kWave / kSub))), dim3(wpb * kWave), 0, as_stream(stream), view(csr),
+                           nodes, times, n, L - 1, hist_len, end_pos, max_window);
+    else
     hipLaunchKernelGGL(k_find_before, dim3((unsigned)ceil_div(n, wpb)), dim3(wpb * kWave), 0, as_stream(stream), view(csr),
                        nodes, times, n, L - 1, hist_len, end_pos, max_window);
     DYGNN_LAUNCH_CHECK();

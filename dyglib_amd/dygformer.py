@@ -183,8 +183,7 @@ class DyGFormer(nn.Module):
         out_dst = torch.empty_like(out_src)
         if B == 0:
             return out_src, out_dst
-        weights = self._weights_struct()
-        packed = self._packed_weights(weights, dev)
+        weights, packed = self._packed_weights(dev)
         ws = self._workspace_for(B, dev)
         taps_struct = None
         if _taps is not None:
@@ -379,14 +378,18 @@ class DyGFormer(nn.Module):
         w.output_w, w.output_b = p(self.output_layer.weight), p(self.output_layer.bias)
         return w
 
-    def _packed_weights(self, weights, dev) -> torch.Tensor:
-        """Kernel-ready weight copy; re-packed whenever any parameter was written (optimizer step,
-        load_state_dict) — detected through the tensors' version counters and addresses."""
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(dev),)
+    def _packed_weights(self, dev):
+        """(ctypes view of the parameters, kernel-ready weight copy); both rebuilt whenever any parameter was written (optimizer
+        step, load_state_dict) — detected through the tensors' version counters and addresses."""
+        plist = self.__dict__.get("_plist")
+        if plist is None:
+            plist = self.__dict__["_plist"] = list(self.parameters())          # parameters are never added after construction
+        key = tuple([(p.data_ptr(), p._version) for p in plist]) + (str(dev),)
         if self._packed is None or self._packed_key != key:
-            for p in self.parameters():
+            for p in plist:
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise _capi.DygnnError("parameters must be contiguous float32")
+            weights = self._weights_cached = self._weights_struct()
             nbytes = self._lib.dygnn_dygformer_packed_bytes(C.byref(self._cfg))
             if nbytes == 0:
                 _capi.check(-1)
@@ -395,7 +398,7 @@ class DyGFormer(nn.Module):
             _capi.check(self._lib.dygnn_dygformer_pack(C.byref(self._cfg), C.byref(weights), self._packed.data_ptr(), nbytes,
                                                        _capi.current_stream_ptr()))
             self._packed_key = key
-        return self._packed
+        return self._weights_cached, self._packed
 
     def _workspace_for(self, B: int, dev) -> torch.Tensor:
         # one workspace per (batch size, stream): calls issued on different HIP streams may overlap

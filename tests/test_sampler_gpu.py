@@ -109,6 +109,32 @@ def test_large_graph_against_oracle_and_edge_cases():
         s.padded_windows(nodes, times, 1, 1)
 
 
+def test_four_queries_per_wave_form_matches_oracle():
+    """Batches of 16,384 queries and more take the 16-lanes-per-query kernels (four searches per wave, sampler.hip): same rows,
+    bit for bit — on a graph with rows from empty to tens of thousands of entries, duplicate timestamps, queries exactly at stored
+    timestamps, and a batch size that is not a multiple of four (idle sub-groups in the last wave)."""
+    from dyglib_amd import get_neighbor_sampler
+    data, _, _ = syn.make_bipartite_graph(300, 40, 60000, seed=3, duplicate_time_every=5, edge_feat_dim=4)
+    s = get_neighbor_sampler(data, "recent", seed=0, device="cuda:0")
+    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    rs = np.random.RandomState(4)
+    idx = rs.randint(0, data.num_interactions, 10001)
+    nodes = np.concatenate([data.src_node_ids[idx], data.dst_node_ids[idx], [0, 0, 1]])          # 20,005 queries
+    times = np.concatenate([data.node_interact_times[idx], data.node_interact_times[idx] + rs.choice([0.0, 1e-3, -1e-3], len(idx)), [0.0, 1e9, -5.0]])
+    assert len(nodes) >= 16384 and len(nodes) % 4 != 0
+    for k in (1, 20, 33):
+        n, e, t = s.get_historical_neighbors(nodes, times, num_neighbors=k)
+        on, oe, ot = orc.get_historical_neighbors_recent(adj, nodes, times, k)
+        np.testing.assert_array_equal(n, on)
+        np.testing.assert_array_equal(e, oe)
+        np.testing.assert_array_equal(t, ot)
+    pid, pe, pt = s.padded_windows(nodes, times, 2, 64)
+    oid, oe, ot = orc.first_hop_windows(adj, nodes, times, 2, 64)
+    np.testing.assert_array_equal(pid, oid)
+    np.testing.assert_array_equal(pe, oe)
+    np.testing.assert_array_equal(pt, ot)
+
+
 def test_cooccurrence_random_rows_against_oracle():
     from dyglib_amd import count_nodes_appearances
     rs = np.random.RandomState(1)

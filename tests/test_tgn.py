@@ -123,3 +123,38 @@ def test_fused_step_equals_negative_then_positive_call():
     assert torch.equal(two.memory_bank.node_memories, one.memory_bank.node_memories)
     assert torch.equal(two.memory_bank.node_last_updated_times, one.memory_bank.node_last_updated_times)
     assert torch.equal(two.memory_bank.msg, one.memory_bank.msg) and torch.equal(two.memory_bank.has_msg, one.memory_bank.has_msg)
+
+
+@pytest.mark.gpu
+def test_hip_mid_size_batches_against_oracle():
+    """BASELINE config 5's call shape on a mid-size graph: B = 200, k = 10, 1 layer, 12 chronological batches from interaction 0 with
+    the memory carried across them (negative call, then positive call, per batch — through the one-call step), against
+    oracle/tgn_oracle.py: every batch's four embedding blocks, and the memory bank + last-update times left behind."""
+    import torch
+    from dyglib_amd import MemoryModel, get_neighbor_sampler
+    from oracle import dygformer_oracle as orc
+    dev, B, K, NB = "cuda:0", 200, 10, 12
+    data, nf, ef = syn.make_bipartite_graph(700, 60, 40_000, seed=11, edge_feat_kind="sparse4", duplicate_time_every=13)
+    params = syn.make_tgn_params(5, nf.shape[0], num_layers=1)
+    sampler = get_neighbor_sampler(data, "recent", seed=1, device=dev)
+    m = MemoryModel(nf, ef, sampler, 100, model_name="TGN", num_layers=1, num_heads=2, dropout=0.1, device=dev)
+    sd = m.state_dict(); sd.update({k: torch.from_numpy(v) for k, v in params.items()}); m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    m.memory_bank.__init_memory_bank__()
+    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    nft, eft = torch.from_numpy(nf), torch.from_numpy(ef)
+    tp = {k: torch.from_numpy(v) for k, v in params.items()}
+    st = tn.TgnState(nf.shape[0], 172)
+    rs, ud = np.random.RandomState(2), np.unique(data.dst_node_ids)
+    with torch.no_grad():
+        for i in range(NB):
+            sl = slice(i * B, (i + 1) * B)
+            s, d, t, e = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl], data.edge_ids[sl]
+            ng = syn.random_negative_dst(rs, ud, B)
+            ps, pd, ns, nd = m.compute_step_embeddings(s, d, s, ng, t, e, num_neighbors=K)
+            ons, ond = tn.tgn_forward(tp, nft, eft, adj, st, s, ng, t, None, False, 1, K, 2)
+            ops, opd = tn.tgn_forward(tp, nft, eft, adj, st, s, d, t, e, True, 1, K, 2)
+            for got, want, what in ((ps, ops, "pos src"), (pd, opd, "pos dst"), (ns, ons, "neg src"), (nd, ond, "neg dst")):
+                close(got.cpu().numpy(), want.numpy(), f"tgn mid-size batch {i} {what}", label=f"tgn mid-size (B=200, k=10, 12 batches) {what}")
+    close(m.memory_bank.node_memories.data.cpu().numpy(), st.M.numpy(), "tgn mid-size memory after 12 batches")
+    close(m.memory_bank.node_last_updated_times.data.cpu().numpy(), st.U.numpy(), "tgn mid-size last update after 12 batches")

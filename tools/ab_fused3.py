@@ -32,23 +32,34 @@ for nm in names:
     if nm:
         m._lib = _capi.load_variant(nm)
     arms.append(m)
-idx = torch.arange(F, device=dev) % wk.n_batches
-src = wk.src_all[idx]
-srcs, dsts, ts = torch.cat([src, src]), torch.cat([wk.dst_all[idx], wk.neg_all[idx]]), torch.cat([wk.t_all[idx], wk.t_all[idx]])
+# AB_COLD=1 (default): every timed call takes the NEXT F batches of the evaluation span, as bench.py does — newer interactions bring feature
+# rows no earlier launch has touched; AB_COLD=0: the same F batches every time (rows hot in L2 / Infinity Cache: reads ~4 % faster)
+COLD = os.environ.get("AB_COLD", "1") != "0"
+def inputs(call):
+    first = (call * F) % max(1, wk.n_batches - F) if COLD else 0
+    idx = (torch.arange(F, device=dev) + first) % wk.n_batches
+    src = wk.src_all[idx]
+    return torch.cat([src, src]), torch.cat([wk.dst_all[idx], wk.neg_all[idx]]), torch.cat([wk.t_all[idx], wk.t_all[idx]])
 outs, times = [], [[] for _ in arms]
 with torch.no_grad():
     for m in arms:
-        outs.append(m.compute_src_dst_node_temporal_embeddings_many(srcs, dsts, ts, pos_neg_halves=PAIRED))
+        outs.append(m.compute_src_dst_node_temporal_embeddings_many(*inputs(0), pos_neg_halves=PAIRED))
     torch.cuda.synchronize()
+    call = 1
     for r in range(rounds):
+        base = call
         for i, m in enumerate(arms):
+            call = base                                   # every arm of a round sees the same inputs
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ins = [inputs(call), inputs(call + 1)]
+            torch.cuda.synchronize()
             e0.record()
-            for _ in range(2):
-                m.compute_src_dst_node_temporal_embeddings_many(srcs, dsts, ts, pos_neg_halves=PAIRED)
+            for x in ins:
+                m.compute_src_dst_node_temporal_embeddings_many(*x, pos_neg_halves=PAIRED)
             e1.record()
             torch.cuda.synchronize()
             times[i].append(e0.elapsed_time(e1) / 2)
+            call += 2
 S = ((wk.L + wk.P - 1) // wk.P) * wk.P
 flop = bench.flops_per_pair(S, S, wk.P) * 2 * F * wk.B
 for i, nm in enumerate(names):

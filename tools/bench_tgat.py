@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--steps", type=int, default=64); ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--steps", type=int, default=64); ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--edges", type=int, default=672447); ap.add_argument("--cpu-seconds", type=float, default=20.0)
 ap.add_argument("--fuse-steps", type=int, default=32)
 a = ap.parse_args()
