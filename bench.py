@@ -675,13 +675,23 @@ def main():
         raise SystemExit("for N>1 launch with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # One process per GPU over RCCL ("nccl").  Rehearsal of the N > 1 path on a box with fewer GPUs than ranks (tests, the builder's
+    # one-GPU box): DYGNN_BENCH_BACKEND=gloo shares the devices round-robin and reduces through gloo — same code path, no xGMI.
+    backend = os.environ.get("DYGNN_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible (RCCL needs one GPU per rank)")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, n_dev)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     wk = DygformerWorkload(args.workload, dev, args.impl)
     B, L, P = wk.B, wk.L, wk.P
@@ -696,7 +706,7 @@ def main():
         "ms_per_step": round(res["elapsed"] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wk.describe(), "batch": B, "max_input_sequence_length": L, "patch_size": P,
-                   "parallelism": f"{world} x edge-batch shard, graph+weights replicated, metric all-reduce over RCCL",
+                   "parallelism": f"{world} x edge-batch shard, graph+weights replicated, metric all-reduce over " + ("RCCL" if backend == "nccl" else backend),
                    "impl": {0: "auto", 1: "generic", 3: "fused3"}.get(args.impl, str(args.impl)), "streams": res["streams"],
                    "steps_per_launch": res["steps_per_launch"], "launches_timed": res["n_launch"],
                    "untimed": f"{max(1, args.prime_launches)} launches of the timed shape + {args.warmup} warm-up steps"},

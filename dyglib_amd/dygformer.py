@@ -176,6 +176,13 @@ class DyGFormer(nn.Module):
             raise AssertionError("src_node_ids, dst_node_ids and node_interact_times must have the same length")
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if (self.training or needs_grad) and B > 0 and _taps is None:
+            if not self.training and not getattr(self, "_warned_eval_grad", False):
+                # eval mode with autograd recording is a legitimate call (gradients without dropout) but ~8x slower than inference:
+                # an evaluation loop that forgot torch.no_grad() should hear about it once
+                import warnings
+                warnings.warn("dyglib_amd.DyGFormer: eval-mode forward with autograd recording runs the training kernels (activations kept "
+                              "for backward); wrap evaluation in torch.no_grad() for the fused inference kernel", RuntimeWarning, stacklevel=2)
+                self._warned_eval_grad = True
             p_drop, seed = self._dropout_and_seed()
             seq_lens = self._seq_lens_side_stream(src_node_ids, dst_node_ids, node_interact_times, src, dst, tms, dev)
             return _TrainFunction.apply(self, src, dst, tms, p_drop, seed, seq_lens, *self.parameters())
