@@ -456,6 +456,181 @@ int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb,
     return DYGNN_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradients, all of them in ONE launch: C_p[m][n] += sum_k A_p[k][m] * B_p[k][n] for a list of problems p that share K (= all
+// token rows of the call).  Both operands are k-major ([token][feature] activations / activation gradients), the outputs are small
+// (<= 800 x 200) and K is long, so the work is cut as (problem, 128-row group of m, n-chunk of <= 208 columns, K-split) and every
+// workgroup runs its whole K-range with 26 accumulator tiles per wave (32 rows x 208 columns): 26 MFMAs per 15 LDS operand reads,
+// against 4 per 4 in the general kernel, and the partial tiles meet by float atomics ONCE per (workgroup, tile) — with all problems of
+// both layers in one grid a K-split of ~11 fills the chip, where the general path split every product 100 ways (400 MB of atomics
+// per step at the chip-wide 1.3 TB/s atomic rate).  Operands arrive by LDS-DMA in the row-contiguous block layout of k_mm_dma
+// (conflict-free ds_read_b32 in the permuted k order); A blocks are private to their wave, the 13 B blocks are shared.  The column
+// sums of A (the bias gradient that belongs to the weight gradient) fall out of the A operand registers.  The finished tiles leave
+// through a wave-private LDS image so that every atomic wave-instruction adds 256 contiguous bytes (MI355X_MICROARCH.md, global float
+// atomics: 64 lanes in 64 rows run 17x slower).
+// ------------------------------------------------------------------------------------------------
+struct DwProblem { const float* A; const float* B; float* C; float* colsum; int lda, ldb, ldc, M, N, ncw; };
+constexpr int kDwMaxProblems = 4 * DYGNN_MAX_LAYERS, kDwMaxItems = 32 * DYGNN_MAX_LAYERS, kDwNS = 3, kDwStage = 22 * 256, kDwLdsBytes = kDwNS * kDwStage * 4;
+struct DwArgs {
+    DwProblem prob[kDwMaxProblems];
+    unsigned short item[kDwMaxItems];      // problem << 12 | m-group << 6 | n-chunk
+    int nitems, K, kchunk;
+};
+__device__ __forceinline__ void dw_dma(const float* gsrc_lane, int lds_float_off_uniform) {      // see v3::dma_frag (dygformer_fused3.hip)
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_groupstaticsize() + 4u * (unsigned)lds_float_off_uniform);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc_lane), "s"(m0v) : "memory", "m0");
+}
+__global__ __launch_bounds__(256, 2) void k_dw_grouped(const DwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];
+    const int it = blockIdx.x % a.nitems, ks = blockIdx.x / a.nitems;
+    const unsigned code = a.item[it];
+    const DwProblem& P = a.prob[code >> 12];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int m0 = 128 * (int)((code >> 6) & 63) + 32 * wave, n0 = P.ncw * (int)(code & 63);
+    const int ncols = P.N - n0 < P.ncw ? P.N - n0 : P.ncw;
+    const bool act = m0 < P.M;
+    const int kbeg = ks * a.kchunk, kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
+    const int nst = (kend - kbeg + 15) >> 4;
+    // this lane's piece of a 16 x 16 block: k = kL, rows / columns 4 (lane & 3) .. +3.  Rows / columns outside the matrix read the zero
+    // page with stride 0, so the per-step address update is one add and nothing is loaded from the argument block inside the loop
+    const int kL = 4 * ((lane >> 2) & 3) + (lane >> 4), rL = 4 * (lane & 3);
+    const int lda = P.lda, ldb = P.ldb;
+    const float* pa[2]; const float* pb[4];
+    size_t sa[2], sb[4];
+    int lb[4];                                           // LDS block of this wave's B loads (21 = dummy)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = m0 + 16 * i + rL;
+        const bool ok = row < P.M;
+        pa[i] = ok ? P.A + (size_t)(kbeg + kL) * lda + row : g_zero_page;
+        sa[i] = ok ? (size_t)16 * lda : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = wave + 4 * u;                      // blocks 0 .. 12; u = 3 exists for wave 0 only
+        const int col = 16 * j + rL;
+        const bool ok = j < 13 && col < ncols;
+        lb[u] = j < 13 ? 8 + j : 21;
+        pb[u] = ok ? P.B + (size_t)(kbeg + kL) * ldb + n0 + col : g_zero_page;
+        sb[u] = ok ? (size_t)16 * ldb : 0;
+    }
+    const int nfull = (kend - kbeg) >> 4;                // steps whose 16 k all exist
+    int slot = 0;                                        // ring slot of the next issue, floats
+    auto issue = [&](int t) {                            // k-step t -> next ring slot; six DMAs per wave whatever t (uniform vmcnt)
+        if (t < nfull) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { dw_dma(pa[i], slot + 256 * (2 * wave + i)); pa[i] += sa[i]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { dw_dma(pb[u], slot + 256 * lb[u]); pb[u] += sb[u]; }
+        } else {                                         // the K tail of the last split, and the two issues beyond the end: zeros
+            const bool kin = t < nst && kbeg + 16 * t + kL < kend;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dw_dma(kin ? pa[i] : g_zero_page, slot + 256 * (2 * wave + i));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dw_dma(kin ? pb[u] : g_zero_page, slot + 256 * lb[u]);
+        }
+        slot = slot == (kDwNS - 1) * kDwStage ? 0 : slot + kDwStage;
+    };
+    f4 acc[2][13];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 13; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    float csum[2] = {0.f, 0.f};
+    issue(0);
+    issue(1);
+    const int roff = 4 * (4 * g + (c >> 2)) + (c & 3);   // element (row c, k = 4 g + r) of a block sits at float 64 r + roff
+    int rslot = 0;                                       // ring slot of the step being multiplied
+    for (int t = 0; t < nst; ++t) {
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");      // this wave's step-t loads have landed; everybody is done with step t - 1
+        issue(t + 2);
+        if (act) {
+            const float* as = dw_lds + rslot + 512 * wave + roff;
+            const float* bs = dw_lds + rslot + 2048 + roff;
+            float av[2][2], bv[2][13];
+            av[0][0] = as[0]; av[0][1] = as[256];
+#pragma unroll
+            for (int j = 0; j < 13; ++j) bv[0][j] = bs[256 * j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r + 1 < 4) {
+                    av[(r + 1) & 1][0] = as[64 * (r + 1)]; av[(r + 1) & 1][1] = as[256 + 64 * (r + 1)];
+#pragma unroll
+                    for (int j = 0; j < 13; ++j) bv[(r + 1) & 1][j] = bs[256 * j + 64 * (r + 1)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                csum[0] += av[r & 1][0]; csum[1] += av[r & 1][1];
+#pragma unroll
+                for (int j = 0; j < 13; ++j) {
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r & 1][0], bv[r & 1][j], acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r & 1][1], bv[r & 1][j], acc[1][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        rslot = rslot == (kDwNS - 1) * kDwStage ? 0 : rslot + kDwStage;
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");          // the trailing zero-page loads have landed, the ring is free
+    if (!act) return;
+    if (P.colsum != nullptr && n0 == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float v = csum[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int m = m0 + 16 * i + c;
+            if (g == 0 && m < P.M) atomicAdd(P.colsum + m, v);
+        }
+    }
+    float* img = dw_lds + wave * (16 * 208);             // wave-private [16][ncols]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 13; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * j + c < ncols) img[(4 * g + r) * ncols + 16 * j + c] = acc[i][j][r];
+        int row = 0, n = lane;
+        for (int f = lane; f < 16 * ncols; f += 64, n += 64) {
+            while (n >= ncols) { n -= ncols; ++row; }
+            const int m = m0 + 16 * i + row;
+            if (m < P.M) atomicAdd(P.C + (size_t)m * P.ldc + n0 + n, img[f]);
+        }
+    }
+}
+
+struct DwList {
+    DwArgs args{};
+    int nprob = 0;
+    bool ok = true;
+    void add(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc, float* colsum) {
+        const bool aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0 && M % 4 == 0 && N % 4 == 0;
+        const int nch = (N + 207) / 208, ncw = (((N + nch - 1) / nch) + 3) & ~3;
+        const int mg = (M + 127) / 128;
+        if (!aligned || nprob >= kDwMaxProblems || mg > 64 || nch > 64 || args.nitems + mg * nch > kDwMaxItems) { ok = false; return; }
+        args.prob[nprob] = DwProblem{A, B, C, colsum, lda, ldb, ldc, M, N, ncw};
+        for (int x = 0; x < mg; ++x)
+            for (int y = 0; y < nch; ++y) args.item[args.nitems++] = (unsigned short)(nprob << 12 | x << 6 | y);
+        ++nprob;
+    }
+    int launch(hipStream_t s, int K) {
+        if (nprob == 0 || K <= 0) return DYGNN_OK;
+        // K-split: about two workgroups per CU over the whole grid, K-ranges of whole 16-wide steps
+        int ksplit = 512 / args.nitems;
+        if (ksplit < 1) ksplit = 1;
+        int kchunk = (((K + ksplit - 1) / ksplit) + 15) & ~15;
+        if (kchunk < 256) kchunk = 256;
+        ksplit = (K + kchunk - 1) / kchunk;
+        args.K = K; args.kchunk = kchunk;
+        DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_grouped), hipFuncAttributeMaxDynamicSharedMemorySize, kDwLdsBytes));
+        hipLaunchKernelGGL(k_dw_grouped, dim3((unsigned)(args.nitems * ksplit)), dim3(256), kDwLdsBytes, s, args);
+        DYGNN_LAUNCH_CHECK();
+        return DYGNN_OK;
+    }
+};
+
 // out[n] += sum_m A[m][n]   (bias gradients): workgroup = 64 columns x a chunk of 256 rows, one atomic per column and workgroup
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ A, int lda, int64_t M, int N, float* __restrict__ out) {
     __shared__ float red[4][64];
@@ -838,8 +1013,8 @@ __global__ void k_pool_bwd(const float* __restrict__ dpooled, int64_t B, int Ts,
 struct Plan {
     WorkspaceLayout wl;       // prefix compatible with window_lengths_device (dims, hist_len, end_pos)
     size_t ids, dts, c0, c1, lut, hid, Pn, Pe, Pt, Pc, X[DYGNN_MAX_LAYERS + 1];
-    struct L { size_t xn0, m0, r0, qkv, S, P, Pd, oa, ao, x1, xn1, m1, r1, hpre, hact, f2; } layer[DYGNN_MAX_LAYERS];
-    size_t pooled, out, dX, dA, dB, dQKV, dH, dpool, dPt, dPc, dlut, total;
+    struct L { size_t xn0, m0, r0, qkv, S, P, Pd, oa, ao, x1, xn1, m1, r1, hpre, hact, f2, dF2, dH, dAo, dQKV; } layer[DYGNN_MAX_LAYERS];
+    size_t pooled, out, dX, dA, dB, dpool, dPt, dPc, dlut, total;
 };
 static Plan make_plan(const Dims& d, int64_t B) {
     Plan p{};
@@ -859,7 +1034,12 @@ static Plan make_plan(const Dims& d, int64_t B) {
         L.hpre = take(M * 4 * d.D * F); L.hact = take(M * 4 * d.D * F); L.f2 = take(M * d.D * F);
     }
     p.pooled = take((size_t)2 * B * d.D * F); p.out = take((size_t)2 * B * d.Fn * F);
-    p.dX = take(M * d.D * F); p.dA = take(M * d.D * F); p.dB = take(M * d.D * F); p.dQKV = take(M * 3 * d.D * F); p.dH = take(M * 4 * d.D * F);
+    p.dX = take(M * d.D * F); p.dA = take(M * d.D * F); p.dB = take(M * d.D * F);
+    // operands of the weight gradients stay alive until the ONE grouped launch at the end of the backward pass (k_dw_grouped): per layer
+    for (int l = 0; l < d.NL; ++l) {
+        auto& L = p.layer[l];
+        L.dF2 = take(M * d.D * F); L.dH = take(M * 4 * d.D * F); L.dAo = take(M * d.D * F); L.dQKV = take(M * 3 * d.D * F);
+    }
     p.dpool = take((size_t)2 * B * d.D * F); p.dPt = take(M * d.P * d.Ft * F); p.dPc = take(M * d.P * d.C * F); p.dlut = take((size_t)(S + 1) * d.C * F);
     p.total = o;
     return p;
@@ -1004,28 +1184,31 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
     if (int rc = mm(s, grad_out_dst, Fn, false, w->output_w, D, false, F32(p.dpool) + B * D, D, (int)B, D, Fn)) return rc;
     float* dX = F32(p.dX);
     EW(k_pool_bwd, M * D, F32(p.dpool), B, Ts, T, D, dX);
+    DwList dw;
     for (int l = d.NL - 1; l >= 0; --l) {
         const dygnn_encoder_layer_weights& Lw = w->layers[l];
         const dygnn_encoder_layer_weights& Lg = grads->layers[l];
         const auto& L = p.layer[l];
         float* dA = F32(p.dA);          // [M][D] scratch
         float* dBf = F32(p.dB);         // [M][D] scratch
-        float* dH = F32(p.dH);          // [M][4D]
-        float* dQKV = F32(p.dQKV);      // [M][3D]
+        float* dF2 = F32(L.dF2);        // [M][D]   operands of this layer's weight gradients: alive until the grouped launch below
+        float* dH = F32(L.dH);          // [M][4D]
+        float* dAo = F32(L.dAo);        // [M][D]
+        float* dQKV = F32(L.dQKV);      // [M][3D]
         // X_{l+1} = X1 + drop(F2), F2 = Hact W2^T + b2
-        EW(k_drop_bwd, M * D, dX, M * D, dr, (uint32_t)(4 * l + 3), dA);                                                       // dF2
-        if (int rc = mm(s, dA, D, true, F32(L.hact), 4 * D, false, G(Lg.ffn1_weight), 4 * D, D, 4 * D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true, G(Lg.ffn1_bias))) return rc;     // dW2 [D][4D]
-        if (int rc = mm(s, dA, D, false, Lw.ffn1_weight, 4 * D, false, dH, 4 * D, (int)M, 4 * D, D)) return rc;                 // dHact
+        EW(k_drop_bwd, M * D, dX, M * D, dr, (uint32_t)(4 * l + 3), dF2);                                                      // dF2
+        dw.add(dF2, D, D, F32(L.hact), 4 * D, 4 * D, G(Lg.ffn1_weight), 4 * D, G(Lg.ffn1_bias));                               // dW2 [D][4D], db2
+        if (int rc = mm(s, dF2, D, false, Lw.ffn1_weight, 4 * D, false, dH, 4 * D, (int)M, 4 * D, D)) return rc;               // dHact
         EW(k_gelu_drop_bwd, M * 4 * D, dH, F32(L.hpre), M * 4 * D, dr, (uint32_t)(4 * l + 2));                                 // dHpre
-        if (int rc = mm(s, dH, 4 * D, true, F32(L.xn1), D, false, G(Lg.ffn0_weight), D, 4 * D, D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true, G(Lg.ffn0_bias))) return rc;           // dW1 [4D][D]
+        dw.add(dH, 4 * D, 4 * D, F32(L.xn1), D, D, G(Lg.ffn0_weight), D, G(Lg.ffn0_bias));                                     // dW1 [4D][D], db1
         if (int rc = mm(s, dH, 4 * D, false, Lw.ffn0_weight, D, false, dBf, D, (int)M, D, 4 * D)) return rc;                    // dxn1
         hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)ceil_div(M, 64)), dim3(256), 8 * D * sizeof(float), s, dBf, F32(L.x1), F32(L.m1), F32(L.r1), Lw.norm1_weight, M, D,
                            dX, G(Lg.norm1_weight), G(Lg.norm1_bias));                                                          // dX is now dX1
         DYGNN_LAUNCH_CHECK();
         // X1 = Xin + drop(Ao), Ao = Oa Wo^T + bo
-        EW(k_drop_bwd, M * D, dX, M * D, dr, (uint32_t)(4 * l + 1), dA);                                                       // dAo
-        if (int rc = mm(s, dA, D, true, F32(L.oa), D, false, G(Lg.out_proj_weight), D, D, D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true, G(Lg.out_proj_bias))) return rc;
-        if (int rc = mm(s, dA, D, false, Lw.out_proj_weight, D, false, dBf, D, (int)M, D, D)) return rc;                        // dOa
+        EW(k_drop_bwd, M * D, dX, M * D, dr, (uint32_t)(4 * l + 1), dAo);                                                      // dAo
+        dw.add(dAo, D, D, F32(L.oa), D, D, G(Lg.out_proj_weight), D, G(Lg.out_proj_bias));                                     // dWo [D][D], dbo
+        if (int rc = mm(s, dAo, D, false, Lw.out_proj_weight, D, false, dBf, D, (int)M, D, D)) return rc;                       // dOa
         // attention: Oa_bh = Pd_bh V_bh ; S_bh = scale Q_bh K_bh^T
         // dV_bh = Pd^T dOa_bh
         if (int rc = mm(s, F32(L.Pd), T, true, dBf, D, false, dQKV + 2 * D, 3 * D, T, hd, T, nullptr, 1.f, 0.f, (int)(B * H), H, (int64_t)H * T * T, (int64_t)T * T,
@@ -1040,12 +1223,15 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
                         (int64_t)T * T, (int64_t)T * 3 * D, hd, (int64_t)T * 3 * D, hd)) return rc;
         if (int rc = mm(s, F32(L.S), T, true, F32(L.qkv), 3 * D, false, dQKV + D, 3 * D, T, hd, T, nullptr, scale, 0.f, (int)(B * H), H, (int64_t)H * T * T,
                         (int64_t)T * T, (int64_t)T * 3 * D, hd, (int64_t)T * 3 * D, hd)) return rc;
-        if (int rc = mm(s, dQKV, 3 * D, true, F32(L.xn0), D, false, G(Lg.in_proj_weight), D, 3 * D, D, (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true, G(Lg.in_proj_bias))) return rc;      // dWin [3D][D]
+        dw.add(dQKV, 3 * D, 3 * D, F32(L.xn0), D, D, G(Lg.in_proj_weight), D, G(Lg.in_proj_bias));                              // dWin [3D][D], dbin
         if (int rc = mm(s, dQKV, 3 * D, false, Lw.in_proj_weight, D, false, dA, D, (int)M, D, 3 * D)) return rc;                // dxn0
         hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)ceil_div(M, 64)), dim3(256), 8 * D * sizeof(float), s, dA, F32(p.X[l]), F32(L.m0), F32(L.r0), Lw.norm0_weight, M, D,
                            dX, G(Lg.norm0_weight), G(Lg.norm0_bias));                                                          // dX is now dX_l
         DYGNN_LAUNCH_CHECK();
     }
+    // every weight gradient of the encoder layers (and its bias gradient) in one grouped split-K launch
+    if (!dw.ok) { set_error("backward: weight-gradient operands are not 16-byte aligned / too many problems"); return DYGNN_E_UNSUPPORTED; }
+    if (int rc = dw.launch(s, (int)M)) return rc;
     // projections: X0[:, ch] = P_ch W_ch^T + b_ch
     const float* PW[4] = {w->proj_node_w, w->proj_edge_w, w->proj_time_w, w->proj_cooc_w};
     float* GW[4] = {G(grads->proj_node_w), G(grads->proj_edge_w), G(grads->proj_time_w), G(grads->proj_cooc_w)};
