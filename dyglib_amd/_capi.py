@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported first: see module docstring)
 from . import _build
 
 DYGNN_MAX_LAYERS = 8
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -103,6 +103,8 @@ SIGNATURES = {
     "dygnn_dygformer_packed_bytes": (C.c_size_t, [C.POINTER(DygformerConfig)]),
     "dygnn_dygformer_pack": (C.c_int, [C.POINTER(DygformerConfig), C.POINTER(DygformerWeights), C.c_void_p, C.c_size_t,
                                        C.c_void_p]),
+    "dygnn_dygformer_repack": (C.c_int, [C.POINTER(DygformerConfig), C.POINTER(DygformerWeights), C.c_void_p, C.c_size_t,
+                                         C.c_void_p]),
     "dygnn_dygformer_workspace_bytes": (C.c_size_t, [C.POINTER(DygformerConfig), C.c_int64]),
     "dygnn_dygformer_workspace_bytes_for": (C.c_size_t, [C.POINTER(DygformerConfig), C.c_int64, C.c_int32]),
     "dygnn_dygformer_forward": (C.c_int, [C.POINTER(DygformerConfig), C.POINTER(DygformerWeights), C.c_void_p, C.POINTER(Csr),
@@ -124,7 +126,7 @@ SIGNATURES = {
     "dygnn_dygformer_train_workspace_bytes": (C.c_size_t, [C.POINTER(DygformerConfig), C.c_int64]),
     "dygnn_dygformer_train_forward": (C.c_int, [C.POINTER(DygformerConfig), C.POINTER(DygformerWeights), C.POINTER(Csr), C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p,
-                                                C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+                                                C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dygnn_dygformer_backward": (C.c_int, [C.POINTER(DygformerConfig), C.POINTER(DygformerWeights), C.POINTER(DygformerWeights), C.c_void_p,
                                            C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dygnn_merge_layer_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

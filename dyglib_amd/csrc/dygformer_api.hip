@@ -10,7 +10,7 @@ int forward_generic(const Dims&, const PackedLayout&, const dygnn_dygformer_weig
                     const dygnn_dygformer_taps*, hipStream_t);
 // dygformer_fused3.hip
 bool fused3_supported(const Dims&);
-int pack_fused3(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, float* packed, hipStream_t);
+int pack_fused3(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, float* packed, hipStream_t, bool reuse_desc);
 int forward_fused3(const Dims&, const PackedLayout&, const dygnn_dygformer_weights*, const float* packed, const dygnn_csr*,
                    const float* node_feat, const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times,
                    int64_t B, int64_t G, int64_t pair_stride, float* out_src, float* out_dst, char* ws, const WorkspaceLayout&,
@@ -202,8 +202,7 @@ extern "C" size_t dygnn_dygformer_workspace_bytes_for(const dygnn_dygformer_conf
     return generic ? wl.total : wl.X;
 }
 
-extern "C" int dygnn_dygformer_pack(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, void* packed,
-                                    size_t packed_bytes, dygnn_stream_t stream) {
+static int pack_impl(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, void* packed, size_t packed_bytes, dygnn_stream_t stream, bool reuse_desc) {
     if (int rc = check_config(cfg)) return rc;
     const Dims d = make_dims(*cfg);
     if (int rc = check_weights(d, w)) return rc;
@@ -215,8 +214,18 @@ extern "C" int dygnn_dygformer_pack(const dygnn_dygformer_config* cfg, const dyg
     }
     if (int rc = pack_generic(d, pl, w, static_cast<float*>(packed), as_stream(stream))) return rc;
     if (fused3_supported(d))
-        if (int rc = pack_fused3(d, pl, w, static_cast<float*>(packed), as_stream(stream))) return rc;
+        if (int rc = pack_fused3(d, pl, w, static_cast<float*>(packed), as_stream(stream), reuse_desc)) return rc;
     return DYGNN_OK;
+}
+
+extern "C" int dygnn_dygformer_pack(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, void* packed,
+                                    size_t packed_bytes, dygnn_stream_t stream) {
+    return pack_impl(cfg, w, packed, packed_bytes, stream, false);
+}
+
+extern "C" int dygnn_dygformer_repack(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, void* packed,
+                                      size_t packed_bytes, dygnn_stream_t stream) {
+    return pack_impl(cfg, w, packed, packed_bytes, stream, true);
 }
 
 extern "C" int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, const void* packed,

@@ -16,10 +16,12 @@
 // The ring protocol: stages of 13 fragments; after the step that finishes a stage every wave waits for its own
 // DMAs, passes one barrier, and issues its share of the stage four ahead.  Steps never straddle the ring end
 // (the packer inserts pad fragments with the same rule the consumer applies).
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
 #include "dygformer_layout.h"
+#include "dropout.h"
 
 // Build-time switch (tools/ab_fused3.py builds the other arm with -DF3_KSKIP=0 to A/B it in one process):
 //   F3_KSKIP     the K = 200 products (QKV, FFN W1) spend 2 instead of 4 MFMAs on their last k-chunk (192..207: only 8 real k), the head-dim
@@ -200,6 +202,7 @@ struct Args {
     int Fn, Fe, Ft, P, L, NL, Tmax;
     int nchunk[4];
     float qscale;
+    train::TrainOut tr;           // training forward only (k_dygformer_fused3<.., true>): the dense activations the backward pass reads
 };
 
 // ---- the shared weight stream ---------------------------------------------------------------------------------
@@ -226,12 +229,15 @@ struct WStream {
     }
     // n fragments consumed (or skipped).  Crossing a stage boundary: wait for own DMAs, barrier (every wave is done with
     // the finished stage, every stage issued before is now visible), then refill the freed ring quarter.
-    __device__ __forceinline__ void advance(int n) {
+    // younger_stores (training forward): this wave has issued exactly that many global stores since its last DMA issue.  vmcnt retires in
+    // issue order, so waiting until only those are outstanding proves the (older) DMAs landed without exposing the stores' latency.
+    __device__ __forceinline__ void advance(int n, int younger_stores = 0) {
         pos += n;
         if (pos >= kRing) pos -= kRing;
         instage += n;
         if (instage >= kStage) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's LDS-DMA has landed before anyone passes the barrier
+            if (younger_stores == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's LDS-DMA has landed before anyone passes the barrier
             __syncthreads();
             do { instage -= kStage; issue(issued); ++issued; } while (instage >= kStage);
         }
@@ -271,7 +277,7 @@ enum { T_WIN = 0, T_PROJ, T_LN, T_QKV, T_QKVBAR, T_ATTN, T_OPROJ, T_FFN, T_POOL,
        T_F_W1 = 16, T_F_GELU, T_F_ADV1, T_F_W2, T_F_ADV2 };      // FFN sub-phases
 
 // LayerNorm of the register-resident X^T (two-pass, biased variance, eps 1e-5); gamma/beta from LDS
-__device__ __forceinline__ void layernorm(f4 (&xn)[kNT], const f4 (&x)[kNT], const float* gamma, const float* beta, int g) {
+__device__ __forceinline__ void layernorm(f4 (&xn)[kNT], const f4 (&x)[kNT], const float* gamma, const float* beta, int g, float& mean_o, float& rstd_o) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < kNT; ++i) s += (x[i].x + x[i].y) + (x[i].z + x[i].w);     // rows 200..207 are exact zeros
@@ -289,6 +295,7 @@ __device__ __forceinline__ void layernorm(f4 (&xn)[kNT], const f4 (&x)[kNT], con
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     const float rstd = 1.0f / sqrtf(v * (1.0f / kD) + 1e-5f);
+    mean_o = mean; rstd_o = rstd;
 #pragma unroll
     for (int i = 0; i < kNT; ++i) {
         const f4 gm = lds4(gamma + 16 * i + 4 * g), bt = lds4(beta + 16 * i + 4 * g);   // zero beyond 200
@@ -390,8 +397,44 @@ __device__ __forceinline__ void tap_store(const f4 (&x)[kNT], float* base, int64
     }
 }
 
+// training forward: the 13 register tiles of a token-owner wave (rows 16 i + 4 g + r of token c) as dense row `row` of a [M][200] buffer
+__device__ __forceinline__ void store_rows(float* base, int64_t row, const f4 (&x)[kNT], int g, bool valid) {
+    if (!valid) return;
+    float* p = base + row * kD + 4 * g;
+#pragma unroll
+    for (int i = 0; i < kNT; ++i)
+        if (i < 12 || g < 2) *reinterpret_cast<f4*>(p + 16 * i) = x[i];
+}
+__device__ __forceinline__ void load_rows(f4 (&x)[kNT], const float* base, int64_t row, int g, bool valid) {
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) x[i] = (valid && (i < 12 || g < 2)) ? ldg4(base + row * kD + 4 * g + 16 * i) : zero4();
+}
+// x = xin + dropout(y + bias) (DyGFormer.py:456, :460), xin re-read from its dense rows, x also written to `out` (or not: nullptr).  Element
+// (row, n = 16 i + 4 g + r) draws mask(site, row * 200 + n) (indices < 2^32: checked by the host).  One tile at a time — load, hash, add,
+// store — so that no more than a tile's worth of temporaries is alive beside the two register sets.
+__device__ __forceinline__ void residual_dropped(f4 (&x)[kNT], const float* xin, float* out, const f4 (&y)[kNT], const float* bias_lds, const train::Drop& dr,
+                                                 uint32_t site, int64_t row, int g, bool valid) {
+    const uint32_t sk = dr.site_key(site), e0 = (uint32_t)row * kD + 4 * g;
+    const float* src = xin + row * kD + 4 * g;
+    float* dst = out ? out + row * kD + 4 * g : nullptr;
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) {
+        const bool on = valid && (i < 12 || g < 2);          // rows 200 .. 207 do not exist
+        f4 v = on ? ldg4(src + 16 * i) : zero4();
+        const f4 bv = lds4(bias_lds + 16 * i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (y[i][r] + bv[r]) * dr.mask32(sk, e0 + 16 * i + r);      // rows >= 200: y and the bias are zero
+        if (on && dst) *reinterpret_cast<f4*>(dst + 16 * i) = v;
+        x[i] = v;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ================================================================================================
-template <int TPW>
+// TR = false: inference.  TR = true: the training forward — dropout at the reference's four sites per layer and every
+// activation the backward pass reads written to HBM as dense rows (a.tr); the residual stream is re-read from those rows after the
+// attention and the FFN block instead of being kept in registers next to the separate accumulators the dropout needs.
+template <int TPW, bool TR>
 __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
     constexpr int NP = 8 / TPW;                  // pairs per workgroup
     constexpr int PT = 512 / NP;                 // threads per pair
@@ -692,6 +735,8 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
     float* Kb = lds + kLdsK;
     float* Vb = lds + kLdsV;
     float* misc = lds + kLdsMisc;
+    const int64_t trow = b * T + 16 * tt + c;                  // training: this lane's dense activation row
+    const bool tokv = pair_ok && 16 * tt + c < T;
 
     if (a.slab_in_ring) {        // the ring was the projection slab until now: start the layer stream (one exposed DMA latency).  Outside the
         ws.open(a.stream, kLdsRing, lane, wave, a.nstages);      // layer loop: inside it the compiler kept the eight DMA addresses live (spilled)
@@ -705,9 +750,19 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
         if (l == 0) __syncthreads();     // the re-zeroing of K/V above is complete before the first K/V rows are written
 
         f4 xn[kNT];
+        float ln_mean = 0.f, ln_rstd = 0.f;
+        if constexpr (TR) { if (l == 0) store_rows(a.tr.X[0], trow, x, g, tokv); }      // X[l + 1] leaves with the FFN's residual add
         ws.fit(2);                       // LN0 gamma, beta: two vector fragments
-        if (active) layernorm(xn, x, lds + kLdsRing + ws.pos * kFrag, lds + kLdsRing + (ws.pos + 1) * kFrag, g);
+        if (active) layernorm(xn, x, lds + kLdsRing + ws.pos * kFrag, lds + kLdsRing + (ws.pos + 1) * kFrag, g, ln_mean, ln_rstd);
         ws.advance(2);
+        f4 ao[kNT];                      // training: the out-projection sum of both heads (dropout applies to the finished sum); unused otherwise
+        if constexpr (TR) {
+            store_rows(a.tr.layer[l].xn0, trow, xn, g, tokv);
+            if (tokv && g == 0) { a.tr.layer[l].m0[trow] = ln_mean; a.tr.layer[l].r0[trow] = ln_rstd; }
+#pragma unroll
+            for (int i = 0; i < kNT; ++i) ao[i] = zero4();
+        }
+        auto& xo = [&]() -> f4 (&)[kNT] { if constexpr (TR) return ao; else return x; }();      // where the out-projection accumulates
         float xk0 = 0.f, xk1 = 0.f;      // LN(x) rows 192..199 as the two packed B operands of the last k-chunk
         if (F3_KSKIP) kpack(xn[kKC - 1], xk0, xk1);
         TACC(T_LN);
@@ -723,6 +778,14 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                 for (int j = 0; j < 7; ++j) qa[j] = lds4(bq + 16 * j);
                 ws.advance(1);
                 qkv_group(qa, xn, xk0, xk1, ws, ringl, active);
+                if constexpr (TR) {
+                    if (tokv) {
+                        float* qp = a.tr.layer[l].qkv + trow * (3 * kD) + kHD * h + 4 * g;
+#pragma unroll
+                        for (int j = 0; j < 7; ++j)
+                            if (j < 6 || g == 0) *reinterpret_cast<f4*>(qp + 16 * j) = qa[j];
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 7; ++j) qa[j] = qa[j] * a.qscale;
             }
@@ -742,6 +805,14 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
 #pragma unroll
                     for (int j = 0; j < 7; ++j)
                         if (j < 6 || g == 0) *reinterpret_cast<f4*>(row + 16 * j) = acc[j];     // cols >= 100 belong to the next row
+                }
+                if constexpr (TR) {
+                    if (tokv) {
+                        float* kp = a.tr.layer[l].qkv + trow * (3 * kD) + (kv + 1) * kD + kHD * h + 4 * g;
+#pragma unroll
+                        for (int j = 0; j < 7; ++j)
+                            if (j < 6 || g == 0) *reinterpret_cast<f4*>(kp + 16 * j) = acc[j];
+                    }
                 }
             }
             TACC(T_QKV);
@@ -800,6 +871,30 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                 const float inv = 1.0f / sum;
 #pragma unroll
                 for (int kt = 0; kt < TPW; ++kt) sa[kt] *= inv;
+                if constexpr (TR) {
+                    // probabilities of query 16 tt + c over keys 16 kt + 4 g + r: row (b H + h) T + query of the [B H][T][T] buffers; the
+                    // dropout of nn.MultiheadAttention acts on them (mask index = offset in that buffer)
+                    const int64_t prow = ((b * 2 + h) * (int64_t)T + 16 * tt + c) * T;
+                    const uint32_t sk = a.tr.dr.site_key((uint32_t)(4 * l + 0));
+                    float* const Pp = a.tr.layer[l].P + prow;
+                    float* const Pdp = a.tr.layer[l].Pd + prow;
+                    const bool vec = (T & 3) == 0;           // rows of T floats: float4 stores need T % 4 == 0 (wave-uniform)
+#pragma unroll
+                    for (int kt = 0; kt < TPW; ++kt) {
+                        const int key0 = 16 * kt + 4 * g;
+                        const f4 pv = sa[kt];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sa[kt][r] *= a.tr.dr.mask32(sk, (uint32_t)prow + key0 + r);
+                        if (vec) {
+                            if (tokv && key0 < T) { *reinterpret_cast<f4*>(Pp + key0) = pv; *reinterpret_cast<f4*>(Pdp + key0) = sa[kt]; }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (tokv && key0 + r < T) { Pp[key0 + r] = pv[r]; Pdp[key0 + r] = sa[kt][r]; }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 // O^T[d][query] = sum_key V[key][d] * P^T[key][query]  (rows >= 100 are junk x zero weight columns)
                 {
                     // V tiles as the A operand: sub-steps (key tile kt, d-tiles 0..3 | 4..6), read one sub-step ahead (8 fragments live, not 14)
@@ -822,6 +917,14 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                         if (half == 0) mma_group<4>(&oa[0], va[st & 1], sa[kt]); else mma_group<3>(&oa[4], va[st & 1], sa[kt]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                }
+            }
+            if constexpr (TR) {
+                if (tokv) {
+                    float* op = a.tr.layer[l].oa + trow * kD + kHD * h + 4 * g;
+#pragma unroll
+                    for (int j = 0; j < 7; ++j)
+                        if (j < 6 || g == 0) *reinterpret_cast<f4*>(op + 16 * j) = oa[j];
                 }
             }
             TACC(T_ATTN);
@@ -854,8 +957,8 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
                                 for (int v = 0; v < 4; ++v) fs[(gi + 1) & 1][v] = lds4(ringl + (pnext + v) * kFrag);
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                            if (F3_KSKIP && j == 6) { if (n == 4) mma_group1<4>(&x[i0], fs[gi & 1], o6); else mma_group1<3>(&x[i0], fs[gi & 1], o6); }
-                            else if (n == 4) mma_group<4>(&x[i0], fs[gi & 1], oa[j]); else mma_group<3>(&x[i0], fs[gi & 1], oa[j]);
+                            if (F3_KSKIP && j == 6) { if (n == 4) mma_group1<4>(&xo[i0], fs[gi & 1], o6); else mma_group1<3>(&xo[i0], fs[gi & 1], o6); }
+                            else if (n == 4) mma_group<4>(&xo[i0], fs[gi & 1], oa[j]); else mma_group<3>(&xo[i0], fs[gi & 1], oa[j]);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -869,17 +972,29 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
         ws.fit(1);
         {
             const float* bo = lds + kLdsRing + ws.pos * kFrag + 4 * g;
+            if constexpr (TR) {          // x1 = x + dropout(Wo O + bo), DyGFormer.py:456; x re-read from the rows stored at the layer's start
+                residual_dropped(x, a.tr.X[l], a.tr.layer[l].x1, ao, bo, a.tr.dr, (uint32_t)(4 * l + 1), trow, g, tokv);
+            } else {
 #pragma unroll
-            for (int i = 0; i < kNT; ++i) x[i] = x[i] + lds4(bo + 16 * i);
+                for (int i = 0; i < kNT; ++i) x[i] = x[i] + lds4(bo + 16 * i);
+            }
         }
         ws.advance(1);
 
         TACC(T_OPROJ);
         // ================= LN1 + FFN: 25 steps of two hidden tiles; W1 fragments [k-chunk][tile], W2 [tile][n-tile] =================
         ws.fit(2);
-        if (active) layernorm(xn, x, lds + kLdsRing + ws.pos * kFrag, lds + kLdsRing + (ws.pos + 1) * kFrag, g);
+        if (active) layernorm(xn, x, lds + kLdsRing + ws.pos * kFrag, lds + kLdsRing + (ws.pos + 1) * kFrag, g, ln_mean, ln_rstd);
         ws.advance(2);
         if (F3_KSKIP) kpack(xn[kKC - 1], xk0, xk1);
+        auto& f2 = xo;                   // where the second FFN product accumulates
+        if constexpr (TR) {
+            store_rows(a.tr.layer[l].xn1, trow, xn, g, tokv);
+            if (tokv && g == 0) { a.tr.layer[l].m1[trow] = ln_mean; a.tr.layer[l].r1[trow] = ln_rstd; }
+#pragma unroll
+            for (int i = 0; i < kNT; ++i) ao[i] = zero4();
+        }
+        const uint32_t sk2 = TR ? a.tr.dr.site_key((uint32_t)(4 * l + 2)) : 0u;
         TACC(T_LN);
         ws.align26();
         // W1(p) | W2(p) per step; W2 accumulates straight into the residual registers (no separate FFN accumulator: 52 VGPRs fewer)
@@ -889,12 +1004,28 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
             if (active) {
                 ffn_w1(h, xn, xk0, xk1, ringl + ws.pos * kFrag, b1s + 32 * p, g);
                 TACC(T_F_W1);
+                if constexpr (TR) {
+                    if (tokv) {
+                        float* hp = a.tr.layer[l].hpre + trow * kHid + 32 * p + 4 * g;
+                        *reinterpret_cast<f4*>(hp) = h[0]; *reinterpret_cast<f4*>(hp + 16) = h[1];
+                    }
+                }
                 gelu_tiles(h);
+                if constexpr (TR) {      // dropout on the activation (DyGFormer.py:458): element (row, hidden unit n) draws mask(site, row * 800 + n)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h[u][r] *= a.tr.dr.mask32(sk2, (uint32_t)trow * kHid + 32 * p + 16 * u + 4 * g + r);
+                    if (tokv) {
+                        float* hp = a.tr.layer[l].hact + trow * kHid + 32 * p + 4 * g;
+                        *reinterpret_cast<f4*>(hp) = h[0]; *reinterpret_cast<f4*>(hp + 16) = h[1];
+                    }
+                }
                 TACC(T_F_GELU);
             }
-            ws.advance(26);
+            ws.advance(26, (TR && active) ? 4 : 0);      // training: the four hpre / hact stores of this step stay in flight through the W2 block
             TACC(T_F_ADV1);
-            if (active) ffn_w2(x, h, ringl + ws.pos * kFrag);
+            if (active) ffn_w2(f2, h, ringl + ws.pos * kFrag);
             TACC(T_F_W2);
             ws.advance(26);
             TACC(T_F_ADV2);
@@ -902,8 +1033,12 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
         ws.fit(1);
         {
             const float* b2 = lds + kLdsRing + ws.pos * kFrag + 4 * g;
+            if constexpr (TR) {          // x_{l+1} = x1 + dropout(W2 h + b2), DyGFormer.py:460; x1 re-read from its rows (not kept through the FFN)
+                residual_dropped(x, a.tr.layer[l].x1, a.tr.X[l + 1], f2, b2, a.tr.dr, (uint32_t)(4 * l + 3), trow, g, tokv);
+            } else {
 #pragma unroll
-            for (int i = 0; i < kNT; ++i) x[i] = x[i] + lds4(b2 + 16 * i);
+                for (int i = 0; i < kNT; ++i) x[i] = x[i] + lds4(b2 + 16 * i);
+            }
         }
         ws.advance(1);
         TACC(T_FFN);
@@ -939,7 +1074,9 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < TPW; ++w) s += pool[((pi * TPW + w) * 2 + side) * kDP + n];
-            mean[pi * 2 * kDP + i] = n < kD ? s / (float)(side ? Td : Ts) : 0.f;
+            const float mv = n < kD ? s / (float)(side ? Td : Ts) : 0.f;
+            mean[pi * 2 * kDP + i] = mv;
+            if constexpr (TR) { if (pair_ok && n < kD) a.tr.pooled[((int64_t)side * a.B + b) * kD + n] = mv; }
         }
         __syncthreads();
         // output layer on the matrix cores: out^T[j][col] = sum_k W[j][k] mean[col][k] + b[j]; wave w owns output tiles w, w+8, ...
@@ -1150,13 +1287,25 @@ static int pack_vec(const float* src, int n_valid, int src_off, float* dst, int 
     return DYGNN_OK;
 }
 
-int pack(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, float* packed, hipStream_t s) {
+// reuse_desc: the weights changed IN PLACE since the last full pack into this buffer (same addresses): the fragment descriptor table that
+// pack left in the buffer is still right, so only the gather kernels run — no host work, no synchronisation (one optimizer step = one repack)
+int pack(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, float* packed, hipStream_t s, bool reuse_desc) {
     const PackLayout3 f = make_layout3(d);
     float* base = packed + pl.fused3;
-    DYGNN_HIP(hipMemsetAsync(base, 0, f.total * sizeof(float), s));
+    if (!reuse_desc) DYGNN_HIP(hipMemsetAsync(base, 0, f.total * sizeof(float), s));
     const float* pb[4] = {w->proj_node_b, w->proj_edge_b, w->proj_time_b, w->proj_cooc_b};
     for (int ch = 0; ch < 4; ++ch)
         if (int rc = pack_vec(pb[ch], kC, 0, base + f.bias_x, kC * ch, kC, s)) return rc;
+    if (reuse_desc) {
+        const FragDesc* dd = reinterpret_cast<const FragDesc*>(base + f.desc);
+        hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.nproj * kFrag, 256)), dim3(256), 0, s, dd + f.nfrag + f.naux, f.nproj, base + f.proj);
+        DYGNN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.nfrag * kFrag, 256)), dim3(256), 0, s, dd, f.nfrag, base + f.stream);
+        DYGNN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.naux * kFrag, 256)), dim3(256), 0, s, dd + f.nfrag, f.naux, base + f.aux);
+        DYGNN_LAUNCH_CHECK();
+        return DYGNN_OK;
+    }
     StreamBuilder sb;
     int nchunk[4];
     build_stream(d, w, sb, nchunk);
@@ -1189,20 +1338,16 @@ int window_lengths_device(const Dims& d, const dygnn_csr* csr, const int64_t* sr
 
 bool fused3_supported(const Dims& d) { return v3::supported(d); }
 size_t fused3_packed_floats(const Dims& d) { return v3::packed_floats(d); }
-int pack_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, float* packed, hipStream_t s) {
-    return v3::pack(d, pl, w, packed, s);
+int pack_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, float* packed, hipStream_t s, bool reuse_desc) {
+    return v3::pack(d, pl, w, packed, s, reuse_desc);
 }
 
-int forward_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, const float* packed,
-                   const dygnn_csr* csr, const float* node_feat, const float* edge_feat, const int64_t* src,
-                   const int64_t* dst, const double* times, int64_t B, int64_t G, int64_t pair_stride, float* out_src, float* out_dst, char* ws,
-                   const WorkspaceLayout& wl, const dygnn_dygformer_taps* taps, hipStream_t s) {
+static int fused3_args(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, const float* packed, const dygnn_csr* csr,
+                       const float* node_feat, const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t B, int64_t G,
+                       float* out_src, float* out_dst, char* ws, const WorkspaceLayout& wl, const dygnn_dygformer_taps* taps, v3::Args& a, v3::PackLayout3& f) {
     using namespace v3;
-    if (!supported(d)) { set_error("fused kernel: unsupported shape"); return DYGNN_E_UNSUPPORTED; }
-    if (int rc = window_lengths_device(d, csr, src, dst, times, B, G, ws, wl, s)) return rc;
-    const PackLayout3 f = make_layout3(d);
+    f = make_layout3(d);
     const float* base = packed + pl.fused3;
-    Args a{};
     a.indptr = csr->indptr; a.nbr = csr->nbr; a.eid = csr->eid; a.ts = csr->ts;
     a.src = src; a.dst = dst; a.times = times;
     a.hist_len = reinterpret_cast<const int32_t*>(ws + wl.hist_len);
@@ -1226,16 +1371,54 @@ int forward_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_
     const int K[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * d.C};
     for (int ch = 0; ch < 4; ++ch) a.nchunk[ch] = (K[ch] + 15) / 16;
     a.qscale = (float)sqrt(1.0 / (double)d.hd);
+    return DYGNN_OK;
+}
+
+int forward_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, const float* packed,
+                   const dygnn_csr* csr, const float* node_feat, const float* edge_feat, const int64_t* src,
+                   const int64_t* dst, const double* times, int64_t B, int64_t G, int64_t pair_stride, float* out_src, float* out_dst, char* ws,
+                   const WorkspaceLayout& wl, const dygnn_dygformer_taps* taps, hipStream_t s) {
+    using namespace v3;
+    if (!supported(d)) { set_error("fused kernel: unsupported shape"); return DYGNN_E_UNSUPPORTED; }
+    if (int rc = window_lengths_device(d, csr, src, dst, times, B, G, ws, wl, s)) return rc;
+    Args a{};
+    PackLayout3 f;
+    if (int rc = fused3_args(d, pl, w, packed, csr, node_feat, edge_feat, src, dst, times, B, G, out_src, out_dst, ws, wl, taps, a, f)) return rc;
     if (taps && taps->seq_lens) DYGNN_HIP(hipMemcpyAsync(taps->seq_lens, ws + wl.dims + 2 * sizeof(int32_t), 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     // per device and cheap: set on every call (a process may drive several GPUs, or call from several threads)
-    DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     if (taps && taps->ev_kernel_start) DYGNN_HIP(hipEventRecord(static_cast<hipEvent_t>(taps->ev_kernel_start), s));
     a.pair_stride = (f.np == 2 && pair_stride > 0) ? pair_stride : 0;      // one pair per workgroup (128 tokens): nothing to share inside a workgroup
-    if (f.np == 2) hipLaunchKernelGGL(k_dygformer_fused3<4>, dim3((unsigned)(a.pair_stride ? a.pair_stride : (B + 1) / 2)), dim3(512), kLdsBytes, s, a);
-    else hipLaunchKernelGGL(k_dygformer_fused3<8>, dim3((unsigned)B), dim3(512), kLdsBytes, s, a);
+    if (f.np == 2) hipLaunchKernelGGL((k_dygformer_fused3<4, false>), dim3((unsigned)(a.pair_stride ? a.pair_stride : (B + 1) / 2)), dim3(512), kLdsBytes, s, a);
+    else hipLaunchKernelGGL((k_dygformer_fused3<8, false>), dim3((unsigned)B), dim3(512), kLdsBytes, s, a);
     DYGNN_LAUNCH_CHECK();
     if (taps && taps->ev_kernel_stop) DYGNN_HIP(hipEventRecord(static_cast<hipEvent_t>(taps->ev_kernel_stop), s));
+    return DYGNN_OK;
+}
+
+// Training forward through the fused kernel (dygformer_train.hip calls this when the shape is supported): one group of B pairs whose
+// window lengths (hist_len / end_pos / dims at the head of `ws`, layout `wl`) the caller has already computed; `lut` = the co-occurrence
+// table of the CURRENT weights; `packed` holds the fragment stream of the current weights (dygnn_dygformer_pack / _repack).
+int forward_fused3_train(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, const float* packed, const dygnn_csr* csr,
+                         const float* node_feat, const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t B,
+                         const float* lut, float* out_src, float* out_dst, char* ws, const WorkspaceLayout& wl, const train::TrainOut& tr, hipStream_t s) {
+    using namespace v3;
+    if (!supported(d)) { set_error("fused training forward: unsupported shape"); return DYGNN_E_UNSUPPORTED; }
+    Args a{};
+    PackLayout3 f;
+    if (int rc = fused3_args(d, pl, w, packed, csr, node_feat, edge_feat, src, dst, times, B, B, out_src, out_dst, ws, wl, nullptr, a, f)) return rc;
+    a.lut = lut;
+    a.tr = tr;
+    a.pair_stride = 0;
+#ifdef DYGNN_STAMPS
+    if (const char* sp = getenv("DYGNN_STAMPS_PTR")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0));   // diagnostic build: [4][8][32] device words
+#endif
+    DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    if (f.np == 2) hipLaunchKernelGGL((k_dygformer_fused3<4, true>), dim3((unsigned)((B + 1) / 2)), dim3(512), kLdsBytes, s, a);
+    else hipLaunchKernelGGL((k_dygformer_fused3<8, true>), dim3((unsigned)B), dim3(512), kLdsBytes, s, a);
+    DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }
 

@@ -12,11 +12,17 @@
 #include <cstdlib>
 #include "dygformer_layout.h"
 #include "gemm.h"
+#include "dropout.h"
 
 namespace dygnn {
 
 int window_lengths_device(const Dims& d, const dygnn_csr* csr, const int64_t* src, const int64_t* dst, const double* times,
                           int64_t B, int64_t G, char* ws, const WorkspaceLayout& wl, hipStream_t s);   // dygformer_generic.hip
+namespace train { struct TrainOut; }
+bool fused3_supported(const Dims& d);                                                                   // dygformer_fused3.hip
+int forward_fused3_train(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, const float* packed, const dygnn_csr* csr,
+                         const float* node_feat, const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t B,
+                         const float* lut, float* out_src, float* out_dst, char* ws, const WorkspaceLayout& wl, const train::TrainOut& tr, hipStream_t s);
 
 namespace train {
 
@@ -650,28 +656,7 @@ static int colsum(hipStream_t s, const float* A, int lda, int64_t M, int N, floa
     return DYGNN_OK;
 }
 
-// ---- dropout: counter-based, identical in forward and backward ----------------------------------------------------
-__device__ __forceinline__ uint32_t rnd32(uint64_t seed, uint32_t site, uint64_t idx) {      // splitmix64 of (seed, site, idx)
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + ((uint64_t)site << 52);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return (uint32_t)((z ^ (z >> 31)) >> 20);
-}
-struct Drop {
-    uint64_t seed; uint32_t thresh; float scale;      // keep iff rnd >= thresh; kept values are multiplied by 1/(1-p)
-    __device__ __forceinline__ float mask(uint32_t site, uint64_t idx) const {
-        if (thresh == 0u) return 1.0f;
-        return rnd32(seed, site, idx) >= thresh ? scale : 0.0f;
-    }
-};
-static Drop make_drop(float p, uint64_t seed) {
-    Drop d;
-    d.seed = seed;
-    d.thresh = p <= 0.f ? 0u : (uint32_t)((double)p * 4294967296.0);
-    d.scale = p <= 0.f ? 1.0f : (float)(1.0 / (1.0 - (double)p));
-    return d;
-}
-
+// ---- dropout: counter-based, identical in forward and backward (dropout.h) ----------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -1075,7 +1060,7 @@ extern "C" size_t dygnn_dygformer_train_workspace_bytes(const dygnn_dygformer_co
 extern "C" int dygnn_dygformer_train_forward(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, const dygnn_csr* csr,
                                              const float* node_feat, const float* edge_feat, const int64_t* src, const int64_t* dst,
                                              const double* times, int64_t batch, float dropout_p, uint64_t seed, float* out_src, float* out_dst,
-                                             void* workspace, size_t workspace_bytes, int32_t* seq_lens_host, dygnn_stream_t stream) {
+                                             void* workspace, size_t workspace_bytes, int32_t* seq_lens_host, const void* packed, dygnn_stream_t stream) {
     if (int rc = check_config(cfg)) return rc;
     const Dims d = make_dims(*cfg);
     if (int rc = supported(d)) return rc;
@@ -1114,6 +1099,22 @@ extern "C" int dygnn_dygformer_train_forward(const dygnn_dygformer_config* cfg, 
                  d.Fn, d.Fe, d.Ft, C, I32(p.ids), I32(p.c0), I32(p.c1), F32(p.dts), F32(p.Pn), F32(p.Pe), F32(p.Pt), F32(p.Pc), csr->num_nodes};
     hipLaunchKernelGGL(k_embed_inputs, dim3((unsigned)B, (unsigned)(T >= 8 ? 8 : 1)), dim3(256), (size_t)5 * S * 4, s, ea);
     DYGNN_LAUNCH_CHECK();
+    // The fused forward (dygformer_fused3.hip, TR = true): one kernel from the windows to the embeddings that also writes every activation
+    // the backward pass reads into this Plan's buffers.  `packed` = the kernel-ready copy of the CURRENT weights (dygnn_dygformer_pack /
+    // dygnn_dygformer_repack); NULL, or a shape the fused kernel does not take: the product-by-product path below.
+    if (packed != nullptr && fused3_supported(d) && !getenv("DYGNN_TRAIN_UNFUSED")) {
+        TrainOut tr{};
+        for (int l = 0; l <= d.NL; ++l) tr.X[l] = F32(p.X[l]);
+        for (int l = 0; l < d.NL; ++l) {
+            const auto& L = p.layer[l];
+            tr.layer[l] = TrainOut::L{F32(L.xn0), F32(L.m0), F32(L.r0), F32(L.qkv), F32(L.P), F32(L.Pd), F32(L.oa), F32(L.x1), F32(L.xn1), F32(L.m1), F32(L.r1),
+                                      F32(L.hpre), F32(L.hact)};
+        }
+        tr.pooled = F32(p.pooled);
+        tr.dr = dr;
+        return forward_fused3_train(d, make_packed_layout(d), w, static_cast<const float*>(packed), csr, node_feat, edge_feat, src, dst, times, B, F32(p.lut),
+                                    out_src, out_dst, ws, p.wl, tr, s);
+    }
     // projections (DyGFormer.py:148-157): X0[:, 50ch : 50ch+50] = P_ch . W_ch^T + b_ch
     const float* PW[4] = {w->proj_node_w, w->proj_edge_w, w->proj_time_w, w->proj_cooc_w};
     const float* PB[4] = {w->proj_node_b, w->proj_edge_b, w->proj_time_b, w->proj_cooc_b};

@@ -60,7 +60,8 @@ class _TrainFunction(torch.autograd.Function):
         dev = src.device
         B = src.numel()
         lib, cfg = model._lib, model._cfg
-        weights = model._weights_struct()
+        # the fused training forward reads the kernel-ready weight copy (refreshed here after an optimizer step, launches only)
+        weights, packed = model._packed_weights(dev)
         nbytes = lib.dygnn_dygformer_train_workspace_bytes(C.byref(cfg), B)
         if nbytes == 0:
             _capi.check(-3)
@@ -74,7 +75,7 @@ class _TrainFunction(torch.autograd.Function):
         rc = lib.dygnn_dygformer_train_forward(C.byref(cfg), C.byref(weights), csr, model.node_raw_features.data_ptr(),
                                                model.edge_raw_features.data_ptr(), src.data_ptr(), dst.data_ptr(), tms.data_ptr(), B,
                                                float(dropout_p), int(seed), out_src.data_ptr(), out_dst.data_ptr(), ws.data_ptr(), nbytes,
-                                               C.cast(seq, C.c_void_p), _capi.current_stream_ptr())
+                                               C.cast(seq, C.c_void_p), packed.data_ptr(), _capi.current_stream_ptr())
         _capi.check(rc)
         ctx.model, ctx.ws, ctx.seq, ctx.B, ctx.dropout_p, ctx.seed = model, ws, seq, B, float(dropout_p), int(seed)
         ctx.param_versions = [(p.data_ptr(), p._version) for p in model.parameters()]
@@ -400,10 +401,19 @@ class DyGFormer(nn.Module):
             nbytes = self._lib.dygnn_dygformer_packed_bytes(C.byref(self._cfg))
             if nbytes == 0:
                 _capi.check(-1)
-            if self._packed is None or self._packed.numel() != nbytes or self._packed.device != dev:
+            fresh = self._packed is None or self._packed.numel() != nbytes or self._packed.device != dev
+            if fresh:
                 self._packed = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-            _capi.check(self._lib.dygnn_dygformer_pack(C.byref(self._cfg), C.byref(weights), self._packed.data_ptr(), nbytes,
-                                                       _capi.current_stream_ptr()))
+            ptrs = tuple(k[0] for k in key[:-1]) + (self._packed.data_ptr(),)
+            # an optimizer step changes the values, not the addresses: the fragment descriptors already in the buffer stay valid and the
+            # refresh is kernel launches only (no host synchronisation inside the training loop)
+            if not fresh and self.__dict__.get("_packed_ptrs") == ptrs:
+                fn = self._lib.dygnn_dygformer_repack
+            else:
+                fn = self._lib.dygnn_dygformer_pack
+            self.__dict__["_packed_ptrs"] = None
+            _capi.check(fn(C.byref(self._cfg), C.byref(weights), self._packed.data_ptr(), nbytes, _capi.current_stream_ptr()))
+            self.__dict__["_packed_ptrs"] = ptrs
             self._packed_key = key
         return self._weights_cached, self._packed
 

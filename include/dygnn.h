@@ -161,6 +161,10 @@ typedef struct dygnn_dygformer_taps {
 size_t dygnn_dygformer_packed_bytes(const dygnn_dygformer_config* cfg_host);
 int dygnn_dygformer_pack(const dygnn_dygformer_config* cfg_host, const dygnn_dygformer_weights* w_host,
                          void* packed, size_t packed_bytes, dygnn_stream_t stream);
+/* The weights changed IN PLACE (an optimizer step: same device addresses as at the last dygnn_dygformer_pack into `packed`):
+ * refresh the copy with kernel launches only — no host work, no synchronisation (train_link_prediction.py:257 runs once per step). */
+int dygnn_dygformer_repack(const dygnn_dygformer_config* cfg_host, const dygnn_dygformer_weights* w_host,
+                           void* packed, size_t packed_bytes, dygnn_stream_t stream);
 
 size_t dygnn_dygformer_workspace_bytes(const dygnn_dygformer_config* cfg_host, int64_t batch);
 /* the same for one implementation choice (`impl` of dygnn_dygformer_forward): the fused kernels need only the per-query search
@@ -296,6 +300,9 @@ int dygnn_tgn_forward_step(const dygnn_tgat_config* cfg_host, const dygnn_tgat_w
  * dygnn_dygformer_train_workspace_bytes; must stay untouched until dygnn_dygformer_backward of the same call returns) and
  * writes this call's padded lengths (S_src, S_dst) to seq_lens_host[2] (one host synchronisation of `stream`) — unless the caller
  * passes them in (both > 0, e.g. obtained with dygnn_window_lengths on a side stream), in which case the call stays asynchronous.
+ * `packed` (may be NULL) = the kernel-ready copy of the CURRENT weights (dygnn_dygformer_pack / dygnn_dygformer_repack): with it, and a
+ * shape the fused kernel takes, the forward is ONE kernel (the inference kernel plus dropout and the activation stores); without it the
+ * product-by-product path runs.  Same results within fp32 rounding, same workspace contents for dygnn_dygformer_backward.
  * dygnn_dygformer_backward: `grads` has the layout of dygnn_dygformer_weights but its pointers are WRITABLE device buffers
  * of the parameter shapes that MUST BE ZERO on entry (the reductions accumulate into them); on return each holds
  * d(sum(out_src*grad_out_src) + sum(out_dst*grad_out_dst))/dparam.
@@ -305,7 +312,8 @@ int dygnn_dygformer_train_forward(const dygnn_dygformer_config* cfg_host, const 
                                   const dygnn_csr* csr_host, const float* node_feat, const float* edge_feat,
                                   const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
                                   float dropout_p, uint64_t seed, float* out_src, float* out_dst,
-                                  void* workspace, size_t workspace_bytes, int32_t* seq_lens_host, dygnn_stream_t stream);
+                                  void* workspace, size_t workspace_bytes, int32_t* seq_lens_host, const void* packed,
+                                  dygnn_stream_t stream);
 int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg_host, const dygnn_dygformer_weights* w_host,
                              const dygnn_dygformer_weights* grads_host, const float* grad_out_src, const float* grad_out_dst,
                              int64_t batch, float dropout_p, uint64_t seed, const int32_t* seq_lens_host,
