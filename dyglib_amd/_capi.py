@@ -128,7 +128,7 @@ SIGNATURES = {
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dygnn_dygformer_backward": (C.c_int, [C.POINTER(DygformerConfig), C.POINTER(DygformerWeights), C.POINTER(DygformerWeights), C.c_void_p,
-                                           C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                           C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "dygnn_merge_layer_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dygnn_tgat_level_entries": (C.c_int, [C.POINTER(TgatConfig), C.c_int64, C.c_void_p, c_i64p, c_i64p, C.c_void_p]),

@@ -237,6 +237,7 @@ struct WStream {
         instage += n;
         if (instage >= kStage) {
             if (younger_stores == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (younger_stores == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's LDS-DMA has landed before anyone passes the barrier
             __syncthreads();
             do { instage -= kStage; issue(issued); ++issued; } while (instage >= kStage);
@@ -347,8 +348,8 @@ __device__ __forceinline__ void gelu_tiles(f4 (&t)[2]) {
 }
 // First product: h[2] (two 16-wide hidden tiles) = b1 + W1 . LN(x); 13 k-chunks of two fragments [k-chunk][tile] read one chunk ahead.
 __device__ __forceinline__ void ffn_w1(f4 (&h)[2], const f4 (&xn)[kNT], const float xk0, const float xk1, const float* abuf, const float* b1p, const int g) {
-    h[0] = lds4(b1p + 4 * g);
-    h[1] = lds4(b1p + 16 + 4 * g);
+    if (b1p != nullptr) { h[0] = lds4(b1p + 4 * g); h[1] = lds4(b1p + 16 + 4 * g); }
+    else { h[0] = zero4(); h[1] = zero4(); }
     f4 sa[2][2];
     sa[0][0] = lds4(abuf); sa[0][1] = lds4(abuf + kFrag);
 #pragma unroll
@@ -1104,6 +1105,149 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
 }
 
 // ================================================================================================
+// Backward of one encoder layer's FFN block (DyGFormer.py:457-460 reversed), token-owner like the forward: a workgroup = 8 waves = 128
+// dense token rows, wave w owns 16 rows x all 200 channels.  In: dX = d loss / d x_{l+1} [M][200].  Per 32-unit hidden step p the two
+// activation-gradient products run register to register from the layer's BACKWARD stream (W2^T then W1^T fragments of the same ring):
+//     dhact^T = W2[:, step]^T . dF2^T,   dhpre = dhact o mask2 o gelu'(hpre),   dxn1^T += W1[step, :]^T . dhpre^T
+// with dF2 = dX o mask3; then LayerNorm-1 backward against the stored statistics, dX <- dX + LN1'(dxn1) in place, and the LN weight /
+// bias gradients (row sums by DPP, the eight waves meet in LDS, one atomic per channel and workgroup).  dF2 and dhpre are written as dense
+// rows for the grouped weight-gradient launch (k_dw_grouped, dygformer_train.hip), which also sums the bias gradients.
+struct FfnBwdArgs {
+    const float* stream; int nstages;
+    int64_t M;
+    float* dX;                                   // [M][200] in: d x_{l+1}; out: d x1
+    const float *hpre, *x1, *m1, *r1;            // forward activations (dense rows)
+    float *dF2, *dH;                             // [M][200], [M][800]
+    float *dgamma, *dbeta;                       // LN1 (accumulated)
+    train::Drop dr; uint32_t site_act, site_out;
+};
+__device__ __forceinline__ float gelu_grad(float v) {                       // d/dv [v Phi(v)] = Phi(v) + v phi(v)
+    const float cdf = 0.5f * (1.0f + erf_as(v * 0.70710678118654752440f));
+    return fmaf(v * 0.39894228040143267794f, __expf(-0.5f * v * v), cdf);
+}
+__global__ __launch_bounds__(512, 2) void k_ffn_bwd(const FfnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * kTokWG + 16 * wave, row = row0 + c;
+    const bool active = row0 < a.M, valid = row < a.M;
+    WStream ws;
+    ws.open(a.stream, kLdsRing, lane, wave, a.nstages);
+    const float* ringl = lds + kLdsRing + lane * 4;
+    // dF2^T = (dX o mask3)^T: the B operand of every W2^T product of the layer
+    f4 d2[kNT];
+    {
+        const uint32_t sk = a.dr.site_key(a.site_out), e0 = (uint32_t)row * kD + 4 * g;
+        const float* src = a.dX + row * kD + 4 * g;
+        float* dst = a.dF2 + row * kD + 4 * g;
+#pragma unroll
+        for (int i = 0; i < kNT; ++i) {
+            const bool on = valid && (i < 12 || g < 2);
+            f4 v = on ? ldg4(src + 16 * i) : zero4();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= a.dr.mask32(sk, e0 + 16 * i + r);
+            if (on) *reinterpret_cast<f4*>(dst + 16 * i) = v;
+            d2[i] = v;
+        }
+    }
+    float dk0 = 0.f, dk1 = 0.f;
+    if (F3_KSKIP) kpack(d2[kKC - 1], dk0, dk1);
+    f4 dxn[kNT];
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) dxn[i] = zero4();
+    const uint32_t sk2 = a.dr.site_key(a.site_act);
+    const float* hrow = a.hpre + row * kHid + 4 * g;
+    float* dhrow = a.dH + row * kHid + 4 * g;
+    f4 hp[2];
+    hp[0] = valid ? ldg4(hrow) : zero4();
+    hp[1] = valid ? ldg4(hrow + 16) : zero4();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the first ring stages have landed
+    __syncthreads();
+#pragma unroll 1
+    for (int p = 0; p < 25; ++p) {
+        f4 dh[2];
+        f4 hn[2];
+        if (active) {
+            // the next step's hidden pre-activations fly through this step (issued first: the two dhpre stores below are then the two
+            // youngest vector-memory operations at the stage barrier)
+            const bool more = valid && p + 1 < 25;
+            hn[0] = more ? ldg4(hrow + 32 * (p + 1)) : zero4();
+            hn[1] = more ? ldg4(hrow + 32 * (p + 1) + 16) : zero4();
+            ffn_w1(dh, d2, dk0, dk1, ringl + ws.pos * kFrag, nullptr, g);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dh[u][r] *= a.dr.mask32(sk2, (uint32_t)row * kHid + 32 * p + 16 * u + 4 * g + r) * gelu_grad(hp[u][r]);
+            if (valid) { *reinterpret_cast<f4*>(dhrow + 32 * p) = dh[0]; *reinterpret_cast<f4*>(dhrow + 32 * p + 16) = dh[1]; }
+        }
+        ws.advance(26, active ? 2 : 0);
+        if (active) {
+            ffn_w2(dxn, dh, ringl + ws.pos * kFrag);
+            hp[0] = hn[0]; hp[1] = hn[1];
+        }
+        ws.advance(26);
+    }
+    // LayerNorm-1 backward (x1 rows and their statistics from the forward): dx1 = dX + rstd (gy - mean(gy) - xhat mean(gy xhat)), gy = dxn gamma
+    ws.fit(1);
+    const float* gam = lds + kLdsRing + ws.pos * kFrag + 4 * g;
+    float* red = lds;                            // [8 waves][2][208] partial sums of dgamma / dbeta (the K/V region is unused here)
+    {
+        const float mean = valid ? a.m1[row] : 0.f, rstd = valid ? a.r1[row] : 0.f;
+        const float* xr = a.x1 + row * kD + 4 * g;
+        f4 xh[kNT];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < kNT; ++i) {
+            const bool on = valid && (i < 12 || g < 2);
+            const f4 xv = on ? ldg4(xr + 16 * i) : zero4();
+            const f4 gm = lds4(gam + 16 * i);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xh[i][r] = on ? (xv[r] - mean) * rstd : 0.f;
+                const float gy = dxn[i][r] * gm[r];
+                s1 += gy; s2 = fmaf(gy, xh[i][r], s2);
+            }
+        }
+        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        const float m1v = s1 * (1.0f / kD), m2v = s2 * (1.0f / kD);
+        float* dxr = a.dX + row * kD + 4 * g;
+#pragma unroll
+        for (int i = 0; i < kNT; ++i) {
+            const bool on = valid && (i < 12 || g < 2);
+            const f4 gm = lds4(gam + 16 * i);
+            f4 pg, pb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pg[r] = row_sum16(dxn[i][r] * xh[i][r]);
+                pb[r] = row_sum16(dxn[i][r]);
+            }
+            if (c == 0) {
+                *reinterpret_cast<f4*>(red + (wave * 2 + 0) * kDP + 16 * i + 4 * g) = pg;
+                *reinterpret_cast<f4*>(red + (wave * 2 + 1) * kDP + 16 * i + 4 * g) = pb;
+            }
+            if (on) {
+                f4 v = ldg4(dxr + 16 * i);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rstd * (dxn[i][r] * gm[r] - m1v - xh[i][r] * m2v);
+                *reinterpret_cast<f4*>(dxr + 16 * i) = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA of this workgroup is left in flight
+    __syncthreads();
+    for (int i = tid; i < 2 * kDP; i += 512) {
+        const int which = i / kDP, n = i % kDP;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += red[(w * 2 + which) * kDP + n];
+        if (n < kD) atomicAdd((which ? a.dbeta : a.dgamma) + n, t);
+    }
+}
+
+// ================================================================================================
 // packing: the stream is described on the host as a list of fragment descriptors in consumption order (with the pad
 // fragments the ring rule asks for), uploaded, and materialised by one kernel.
 // ================================================================================================
@@ -1114,6 +1258,7 @@ struct FragDesc {
     int c0, cmax;         //                  col = c0 + 4g + t, valid iff col < cmax
     int kmode;            // 1: last chunk of a K = 200 product, 8 real k in two MFMAs: t < 2: col = c0 + {0,4,1,5}[g] + 2t, t >= 2: zero (mma_group2)
                           // 2: last chunk of a head-dim (100) contraction, 4 real k in one MFMA: t = 0: col = c0 + g, t >= 1: zero (mma_group1)
+                          // +4: transposed source, element (row, col) = src[col * ld + row] (the backward stream: W^T fragments of the same tensors)
 };
 
 __global__ void k_pack_stream(const FragDesc* __restrict__ desc, int64_t nfrag, float* __restrict__ dst) {
@@ -1124,12 +1269,12 @@ __global__ void k_pack_stream(const FragDesc* __restrict__ desc, int64_t nfrag, 
     const int c = lane & 15, g = lane >> 4;
     const int row = d.r0 + c;
     int col = d.c0 + 4 * g + t;
-    if (d.kmode == 1) col = t < 2 ? d.c0 + (g & 1) * 4 + (g >> 1) + 2 * t : d.cmax;
-    if (d.kmode == 2) col = t == 0 ? d.c0 + g : d.cmax;
+    if ((d.kmode & 3) == 1) col = t < 2 ? d.c0 + (g & 1) * 4 + (g >> 1) + 2 * t : d.cmax;
+    if ((d.kmode & 3) == 2) col = t == 0 ? d.c0 + g : d.cmax;
     float v = 0.f;
     if (d.src != nullptr) {
         if (d.ld < 0) { const int e = (int)(idx & 255); if (e < d.rmax) v = d.src[d.c0 + e]; }
-        else if (row >= 0 && row < d.rmax && col < d.cmax) v = d.src[(size_t)row * d.ld + col];
+        else if (row >= 0 && row < d.rmax && col < d.cmax) v = (d.kmode & 4) ? d.src[(size_t)col * d.ld + row] : d.src[(size_t)row * d.ld + col];
     }
     dst[idx] = v;
 }
@@ -1196,6 +1341,20 @@ static void build_stream(const Dims& d, const dygnn_dygformer_weights* w, Stream
     }
 }
 
+// backward stream of layer l's FFN block (k_ffn_bwd): per hidden step p the W2^T block [k-chunk over channels][hidden tile u] and the
+// W1^T block [hidden chunk u][channel tile i] — the transposes of the forward's two blocks, cut from the same tensors — then LN1's gamma
+static void build_bwd_ffn(const dygnn_encoder_layer_weights& L, StreamBuilder& sb) {
+    for (int p = 0; p < 25; ++p) {
+        for (int kc = 0; kc < kKC; ++kc)
+            for (int u = 0; u < 2; ++u) sb.put(L.ffn1_weight, kHid, 16 * (2 * p + u), kHid, 16 * kc, kD, ((F3_KSKIP && kc == kKC - 1) ? 1 : 0) | 4);
+        for (int u = 0; u < 2; ++u)
+            for (int i = 0; i < kNT; ++i) sb.put(L.ffn0_weight, kD, 16 * i, kD, 16 * (2 * p + u), kHid, 4);
+    }
+    sb.fit(1);
+    sb.put_vec(L.norm1_weight, 0, kD);
+}
+constexpr int64_t kBwdFfnFrags = 25 * 52 + 1;
+
 // projection fragments in step order (channels node, time, edge, cooc; 4 tiles per k-chunk), staged by slabs
 static void build_proj(const Dims& d, const dygnn_dygformer_weights* w, StreamBuilder& sb) {
     const float* pw[4] = {w->proj_node_w, w->proj_edge_w, w->proj_time_w, w->proj_cooc_w};
@@ -1222,6 +1381,7 @@ struct PackLayout3 {       // float offsets relative to PackedLayout.fused3
     size_t proj; int64_t nproj;                    // projection fragments
     int scr_floats, slab_chunks;                   // LDS split of the K/V region during the prologue
     int np, slab_in_ring;                          // pairs per workgroup (0: shape unsupported); slab placed in the weight ring
+    size_t bwd[DYGNN_MAX_LAYERS]; int bwd_nstages;  // per layer: the backward stream of its FFN block (training only)
     size_t desc;           // FragDesc table (device copy), 8-byte aligned
     size_t total;
 };
@@ -1255,7 +1415,9 @@ static PackLayout3 make_layout3(const Dims& d) {
     f.nproj = 0;
     for (int ch = 0; ch < 4; ++ch) f.nproj += 4 * (int64_t)((K[ch] + 15) / 16);
     f.proj = take((size_t)f.nproj * kFrag);
-    f.desc = take(((size_t)(f.nfrag + f.naux + f.nproj) * sizeof(FragDesc) + 3) / 4);
+    f.bwd_nstages = (int)((kBwdFfnFrags + kStage - 1) / kStage);
+    for (int l = 0; l < d.NL; ++l) f.bwd[l] = take((size_t)(f.bwd_nstages + 1) * kStage * kFrag);
+    f.desc = take(((size_t)(f.nfrag + f.naux + f.nproj + d.NL * kBwdFfnFrags) * sizeof(FragDesc) + 3) / 4);
     // prologue LDS split: pairs per workgroup, window arrays (5 x 2 sides x Smax ints per pair), projection slab
     const int per_pair = 5 * 2 * ((d.Smax + 3) & ~3);
     f.np = 0; f.slab_in_ring = 0; f.scr_floats = 0; f.slab_chunks = 0;
@@ -1304,6 +1466,11 @@ int pack(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w
         DYGNN_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.naux * kFrag, 256)), dim3(256), 0, s, dd + f.nfrag, f.naux, base + f.aux);
         DYGNN_LAUNCH_CHECK();
+        for (int l = 0; l < d.NL; ++l) {
+            hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(kBwdFfnFrags * kFrag, 256)), dim3(256), 0, s, dd + f.nfrag + f.naux + f.nproj + l * kBwdFfnFrags,
+                               kBwdFfnFrags, base + f.bwd[l]);
+            DYGNN_LAUNCH_CHECK();
+        }
         return DYGNN_OK;
     }
     StreamBuilder sb;
@@ -1327,7 +1494,20 @@ int pack(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w
     DYGNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.naux * kFrag, 256)), dim3(256), 0, s, ddesc + f.nfrag, f.naux, base + f.aux);
     DYGNN_LAUNCH_CHECK();
-    DYGNN_HIP(hipStreamSynchronize(s));     // the descriptor table is copied from this call's host vector
+    std::vector<FragDesc> bw;
+    for (int l = 0; l < d.NL; ++l) {
+        StreamBuilder sbb;
+        build_bwd_ffn(w->layers[l], sbb);
+        if ((int64_t)sbb.frags.size() != kBwdFfnFrags) { set_error("pack: backward stream builder mismatch"); return DYGNN_E_INVALID; }
+        bw.insert(bw.end(), sbb.frags.begin(), sbb.frags.end());
+    }
+    FragDesc* bdesc = ddesc + f.nfrag + f.naux + f.nproj;
+    DYGNN_HIP(hipMemcpyAsync(bdesc, bw.data(), bw.size() * sizeof(FragDesc), hipMemcpyHostToDevice, s));
+    for (int l = 0; l < d.NL; ++l) {
+        hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(kBwdFfnFrags * kFrag, 256)), dim3(256), 0, s, bdesc + l * kBwdFfnFrags, kBwdFfnFrags, base + f.bwd[l]);
+        DYGNN_LAUNCH_CHECK();
+    }
+    DYGNN_HIP(hipStreamSynchronize(s));     // the descriptor tables are copied from this call's host vectors
     return DYGNN_OK;
 }
 
@@ -1394,6 +1574,22 @@ int forward_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_
     else hipLaunchKernelGGL((k_dygformer_fused3<8, false>), dim3((unsigned)B), dim3(512), kLdsBytes, s, a);
     DYGNN_LAUNCH_CHECK();
     if (taps && taps->ev_kernel_stop) DYGNN_HIP(hipEventRecord(static_cast<hipEvent_t>(taps->ev_kernel_stop), s));
+    return DYGNN_OK;
+}
+
+// FFN block of layer l, backward (k_ffn_bwd); the caller's buffers are the dense rows of dygformer_train.hip's Plan
+int ffn_backward_fused3(const Dims& d, const PackedLayout& pl, const float* packed, int l, int64_t M, float* dX, const float* hpre, const float* x1,
+                        const float* m1, const float* r1, float* dF2, float* dH, float* dgamma, float* dbeta, const train::Drop& dr, hipStream_t s) {
+    using namespace v3;
+    if (!supported(d)) { set_error("fused FFN backward: unsupported shape"); return DYGNN_E_UNSUPPORTED; }
+    const PackLayout3 f = make_layout3(d);
+    FfnBwdArgs a{};
+    a.stream = packed + pl.fused3 + f.bwd[l]; a.nstages = f.bwd_nstages;
+    a.M = M; a.dX = dX; a.hpre = hpre; a.x1 = x1; a.m1 = m1; a.r1 = r1; a.dF2 = dF2; a.dH = dH; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.dr = dr; a.site_act = (uint32_t)(4 * l + 2); a.site_out = (uint32_t)(4 * l + 3);
+    DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffn_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    hipLaunchKernelGGL(k_ffn_bwd, dim3((unsigned)ceil_div(M, (int64_t)kTokWG)), dim3(512), kLdsBytes, s, a);
+    DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }
 

@@ -20,6 +20,9 @@ int window_lengths_device(const Dims& d, const dygnn_csr* csr, const int64_t* sr
                           int64_t B, int64_t G, char* ws, const WorkspaceLayout& wl, hipStream_t s);   // dygformer_generic.hip
 namespace train { struct TrainOut; }
 bool fused3_supported(const Dims& d);                                                                   // dygformer_fused3.hip
+namespace train { struct Drop; }
+int ffn_backward_fused3(const Dims& d, const PackedLayout& pl, const float* packed, int l, int64_t M, float* dX, const float* hpre, const float* x1,
+                        const float* m1, const float* r1, float* dF2, float* dH, float* dgamma, float* dbeta, const train::Drop& dr, hipStream_t s);
 int forward_fused3_train(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, const float* packed, const dygnn_csr* csr,
                          const float* node_feat, const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t B,
                          const float* lut, float* out_src, float* out_dst, char* ws, const WorkspaceLayout& wl, const train::TrainOut& tr, hipStream_t s);
@@ -1102,7 +1105,7 @@ extern "C" int dygnn_dygformer_train_forward(const dygnn_dygformer_config* cfg, 
     // The fused forward (dygformer_fused3.hip, TR = true): one kernel from the windows to the embeddings that also writes every activation
     // the backward pass reads into this Plan's buffers.  `packed` = the kernel-ready copy of the CURRENT weights (dygnn_dygformer_pack /
     // dygnn_dygformer_repack); NULL, or a shape the fused kernel does not take: the product-by-product path below.
-    if (packed != nullptr && fused3_supported(d) && !getenv("DYGNN_TRAIN_UNFUSED")) {
+    if (packed != nullptr && fused3_supported(d) && (uint64_t)M * 4 * D < (1ull << 32) && (uint64_t)B * H * T * T < (1ull << 32) && !getenv("DYGNN_TRAIN_UNFUSED")) {
         TrainOut tr{};
         for (int l = 0; l <= d.NL; ++l) tr.X[l] = F32(p.X[l]);
         for (int l = 0; l < d.NL; ++l) {
@@ -1156,7 +1159,7 @@ extern "C" int dygnn_dygformer_train_forward(const dygnn_dygformer_config* cfg, 
 
 extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, const dygnn_dygformer_weights* grads,
                                         const float* grad_out_src, const float* grad_out_dst, int64_t batch, float dropout_p, uint64_t seed,
-                                        const int32_t* seq_lens_host, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
+                                        const int32_t* seq_lens_host, void* workspace, size_t workspace_bytes, const void* packed, dygnn_stream_t stream) {
     if (int rc = check_config(cfg)) return rc;
     const Dims d = make_dims(*cfg);
     if (int rc = supported(d)) return rc;
@@ -1186,6 +1189,8 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
     float* dX = F32(p.dX);
     EW(k_pool_bwd, M * D, F32(p.dpool), B, Ts, T, D, dX);
     DwList dw;
+    // `packed` = the kernel-ready copy of the weights the forward ran with (it holds the backward fragment streams too): the FFN blocks run fused
+    const bool fused = packed != nullptr && fused3_supported(d) && (uint64_t)M * 4 * D < (1ull << 32) && !getenv("DYGNN_TRAIN_UNFUSED");
     for (int l = d.NL - 1; l >= 0; --l) {
         const dygnn_encoder_layer_weights& Lw = w->layers[l];
         const dygnn_encoder_layer_weights& Lg = grads->layers[l];
@@ -1197,15 +1202,20 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
         float* dAo = F32(L.dAo);        // [M][D]
         float* dQKV = F32(L.dQKV);      // [M][3D]
         // X_{l+1} = X1 + drop(F2), F2 = Hact W2^T + b2
-        EW(k_drop_bwd, M * D, dX, M * D, dr, (uint32_t)(4 * l + 3), dF2);                                                      // dF2
         dw.add(dF2, D, D, F32(L.hact), 4 * D, 4 * D, G(Lg.ffn1_weight), 4 * D, G(Lg.ffn1_bias));                               // dW2 [D][4D], db2
-        if (int rc = mm(s, dF2, D, false, Lw.ffn1_weight, 4 * D, false, dH, 4 * D, (int)M, 4 * D, D)) return rc;               // dHact
-        EW(k_gelu_drop_bwd, M * 4 * D, dH, F32(L.hpre), M * 4 * D, dr, (uint32_t)(4 * l + 2));                                 // dHpre
         dw.add(dH, 4 * D, 4 * D, F32(L.xn1), D, D, G(Lg.ffn0_weight), D, G(Lg.ffn0_bias));                                     // dW1 [4D][D], db1
-        if (int rc = mm(s, dH, 4 * D, false, Lw.ffn0_weight, D, false, dBf, D, (int)M, D, 4 * D)) return rc;                    // dxn1
-        hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)ceil_div(M, 64)), dim3(256), 8 * D * sizeof(float), s, dBf, F32(L.x1), F32(L.m1), F32(L.r1), Lw.norm1_weight, M, D,
-                           dX, G(Lg.norm1_weight), G(Lg.norm1_bias));                                                          // dX is now dX1
-        DYGNN_LAUNCH_CHECK();
+        if (fused) {      // the whole block in one kernel (dygformer_fused3.hip: k_ffn_bwd): dF2, dHpre written for the grouped launch, dX <- dX1 in place
+            if (int rc = ffn_backward_fused3(d, make_packed_layout(d), static_cast<const float*>(packed), l, M, dX, F32(L.hpre), F32(L.x1), F32(L.m1), F32(L.r1), dF2, dH,
+                                             G(Lg.norm1_weight), G(Lg.norm1_bias), dr, s)) return rc;
+        } else {
+            EW(k_drop_bwd, M * D, dX, M * D, dr, (uint32_t)(4 * l + 3), dF2);                                                  // dF2
+            if (int rc = mm(s, dF2, D, false, Lw.ffn1_weight, 4 * D, false, dH, 4 * D, (int)M, 4 * D, D)) return rc;           // dHact
+            EW(k_gelu_drop_bwd, M * 4 * D, dH, F32(L.hpre), M * 4 * D, dr, (uint32_t)(4 * l + 2));                             // dHpre
+            if (int rc = mm(s, dH, 4 * D, false, Lw.ffn0_weight, D, false, dBf, D, (int)M, D, 4 * D)) return rc;                // dxn1
+            hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)ceil_div(M, 64)), dim3(256), 8 * D * sizeof(float), s, dBf, F32(L.x1), F32(L.m1), F32(L.r1), Lw.norm1_weight, M, D,
+                               dX, G(Lg.norm1_weight), G(Lg.norm1_bias));                                                      // dX is now dX1
+            DYGNN_LAUNCH_CHECK();
+        }
         // X1 = Xin + drop(Ao), Ao = Oa Wo^T + bo
         EW(k_drop_bwd, M * D, dX, M * D, dr, (uint32_t)(4 * l + 1), dAo);                                                      // dAo
         dw.add(dAo, D, D, F32(L.oa), D, D, G(Lg.out_proj_weight), D, G(Lg.out_proj_bias));                                     // dWo [D][D], dbo

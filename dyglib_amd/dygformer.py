@@ -78,6 +78,7 @@ class _TrainFunction(torch.autograd.Function):
                                                C.cast(seq, C.c_void_p), packed.data_ptr(), _capi.current_stream_ptr())
         _capi.check(rc)
         ctx.model, ctx.ws, ctx.seq, ctx.B, ctx.dropout_p, ctx.seed = model, ws, seq, B, float(dropout_p), int(seed)
+        ctx.packed = packed
         ctx.param_versions = [(p.data_ptr(), p._version) for p in model.parameters()]
         return out_src, out_dst
 
@@ -102,7 +103,7 @@ class _TrainFunction(torch.autograd.Function):
         weights = model._weights_struct()
         rc = model._lib.dygnn_dygformer_backward(C.byref(model._cfg), C.byref(weights), C.byref(gstruct), g_src.data_ptr(), g_dst.data_ptr(), ctx.B,
                                                  ctx.dropout_p, ctx.seed, C.cast(ctx.seq, C.c_void_p), ctx.ws.data_ptr(), ctx.ws.numel(),
-                                                 _capi.current_stream_ptr())
+                                                 ctx.packed.data_ptr(), _capi.current_stream_ptr())
         _capi.check(rc)
         ctx.ws = None
         return (None, None, None, None, None, None, None, *grads)

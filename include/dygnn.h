@@ -306,7 +306,8 @@ int dygnn_tgn_forward_step(const dygnn_tgat_config* cfg_host, const dygnn_tgat_w
  * dygnn_dygformer_backward: `grads` has the layout of dygnn_dygformer_weights but its pointers are WRITABLE device buffers
  * of the parameter shapes that MUST BE ZERO on entry (the reductions accumulate into them); on return each holds
  * d(sum(out_src*grad_out_src) + sum(out_dst*grad_out_dst))/dparam.
- * The feature tables receive no gradient (constants in the reference, models/DyGFormer.py:28-29). */
+ * The feature tables receive no gradient (constants in the reference, models/DyGFormer.py:28-29).
+ * `packed` (may be NULL): the buffer the forward was given; with it the FFN blocks run backward as one fused kernel per layer. */
 size_t dygnn_dygformer_train_workspace_bytes(const dygnn_dygformer_config* cfg_host, int64_t batch);
 int dygnn_dygformer_train_forward(const dygnn_dygformer_config* cfg_host, const dygnn_dygformer_weights* w_host,
                                   const dygnn_csr* csr_host, const float* node_feat, const float* edge_feat,
@@ -317,7 +318,7 @@ int dygnn_dygformer_train_forward(const dygnn_dygformer_config* cfg_host, const 
 int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg_host, const dygnn_dygformer_weights* w_host,
                              const dygnn_dygformer_weights* grads_host, const float* grad_out_src, const float* grad_out_dst,
                              int64_t batch, float dropout_p, uint64_t seed, const int32_t* seq_lens_host,
-                             void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
+                             void* workspace, size_t workspace_bytes, const void* packed, dygnn_stream_t stream);
 
 /* Caller-side link predictor, fused: sigmoid(MergeLayer(a,b)) with
  * MergeLayer = fc2(relu(fc1(cat(a,b)))) (models/modules.py:57-68; evaluate_models_utils.py:140-141).
