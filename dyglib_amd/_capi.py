@@ -131,6 +131,10 @@ SIGNATURES = {
                                            C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "dygnn_merge_layer_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dygnn_merge_layer_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dygnn_merge_layer_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dygnn_tgat_level_entries": (C.c_int, [C.POINTER(TgatConfig), C.c_int64, C.c_void_p, c_i64p, c_i64p, C.c_void_p]),
     "dygnn_link_metrics_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "dygnn_link_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

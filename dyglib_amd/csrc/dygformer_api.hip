@@ -35,7 +35,7 @@ static int check_weights(const Dims& d, const dygnn_dygformer_weights* w) {
 __global__ __launch_bounds__(256) void k_merge_sigmoid(const float* __restrict__ a, const float* __restrict__ b, int dim, int hidden,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
                                                          const float* __restrict__ w2, const float* __restrict__ b2,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, int sig) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* x = reinterpret_cast<float*>(smem);          // [2*dim]
     float* red = x + 2 * dim;                           // [4]
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_merge_sigmoid(const float* __restrict__
     if (threadIdx.x == 0) {
         float z = b2[0];
         for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) z += red[wv];
-        out[r] = 1.0f / (1.0f + expf(-z));
+        out[r] = sig ? 1.0f / (1.0f + expf(-z)) : z;
     }
 }
 
@@ -68,7 +68,7 @@ using mf4 = __attribute__((ext_vector_type(4))) float;
 __global__ __launch_bounds__(256) void k_merge_sigmoid_mfma(const float* __restrict__ a, const float* __restrict__ b, int64_t n_rows, int dim,
                                                               int hidden, const float* __restrict__ w1, const float* __restrict__ b1,
                                                               const float* __restrict__ w2, const float* __restrict__ b2,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, int sig) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_merge_sigmoid_mfma(const float* __restr
     }
     z += __shfl_xor(z, 16, 64);
     z += __shfl_xor(z, 32, 64);
-    if (g == 0 && mv) out[m] = 1.0f / (1.0f + expf(-(z + b2[0])));
+    if (g == 0 && mv) out[m] = sig ? 1.0f / (1.0f + expf(-(z + b2[0]))) : z + b2[0];
 }
 
 
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_merge_sigmoid_mfma(const float* __restr
 __global__ __launch_bounds__(256) void k_merge_sigmoid_mid(const float* __restrict__ a, const float* __restrict__ b, int64_t n_rows, int dim,
                                                              int hidden, const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w2, const float* __restrict__ b2,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, int sig) {
     __shared__ float zpart[4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -173,7 +173,167 @@ __global__ __launch_bounds__(256) void k_merge_sigmoid_mid(const float* __restri
     z += __shfl_xor(z, 32, 64);
     if (g == 0) zpart[wave][c] = z;
     __syncthreads();
-    if (wave == 0 && g == 0 && mv) out[m] = 1.0f / (1.0f + expf(-(((zpart[0][c] + zpart[1][c]) + (zpart[2][c] + zpart[3][c])) + b2[0])));
+    if (wave == 0 && g == 0 && mv) {
+        const float z = ((zpart[0][c] + zpart[1][c]) + (zpart[2][c] + zpart[3][c])) + b2[0];
+        out[m] = sig ? 1.0f / (1.0f + expf(-z)) : z;
+    }
+}
+
+// Backward of the link predictor z = fc2(relu(fc1(cat(a, b)))) for the training step (train_link_prediction.py:241-257; models/modules.py:57-68):
+// given g = dL/dz [n] it produces da, db [n][dim] and the four parameter gradients.  The whole head is 0.1 GFLOP per step, so this is plain
+// FMA code organised around its memory shapes, in two launches and without atomics (float atomics take ~3,000 cycles to retire under load and
+// every later load of the wave waits behind them: a first single-kernel version with one atomic per dfc1 element spent 80 us on that):
+//   k_merge_bwd_w : one workgroup = 8 hidden units j, ALL rows.  Per block of 256 rows: thread = row recomputes the 8 pre-activations
+//                   (fc1 rows from LDS) and leaves dh = g w2 [pre > 0] in LDS and in `dh` [n][hidden]; thread = input feature k then
+//                   accumulates dfc1[j][k] += dh[row][j] cat[row][k] over the block (coalesced feature reads).  Plain stores at the end;
+//                   dfc1_b, dfc2_w by wave reductions, dfc2_b by workgroup 0.
+//   k_merge_bwd_x : one workgroup = 8 rows: dcat[row][k] = sum_j dh[row][j] fc1[j][k], thread = k, coalesced fc1 reads.
+constexpr int kMergeJ = 8, kMergeRows = 8;
+__global__ __launch_bounds__(256) void k_merge_bwd_w(const float* __restrict__ a, const float* __restrict__ b, int64_t n, int dim, int hidden,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                      const float* __restrict__ gz, float* __restrict__ dh, float* __restrict__ dw1,
+                                                      float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2) {
+    extern __shared__ __attribute__((aligned(16))) float msm[];
+    const int K = 2 * dim, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j0 = blockIdx.x * kMergeJ;
+    float* wj = msm;                          // [8][K] fc1 rows of this workgroup's hidden units
+    float* dhs = wj + kMergeJ * K;            // [256][8]
+    float* red = dhs + 256 * kMergeJ;         // [4 waves][2][8] (+ 4 for dfc2_b)
+    for (int idx = tid; idx < kMergeJ * K; idx += 256) {
+        const int j = idx / K;
+        wj[idx] = j0 + j < hidden ? w1[(size_t)(j0 + j) * K + (idx - j * K)] : 0.f;
+    }
+    float bj[kMergeJ], vj[kMergeJ];
+#pragma unroll
+    for (int j = 0; j < kMergeJ; ++j) { bj[j] = j0 + j < hidden ? b1[j0 + j] : 0.f; vj[j] = j0 + j < hidden ? w2[j0 + j] : 0.f; }
+    float accw[2][kMergeJ];                   // dfc1[j0 + j][k], k = tid and tid + 256
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < kMergeJ; ++j) accw[q][j] = 0.f;
+    float sb[kMergeJ], sw[kMergeJ], sg = 0.f;  // this thread's share of dfc1_b, dfc2_w, dfc2_b
+#pragma unroll
+    for (int j = 0; j < kMergeJ; ++j) { sb[j] = 0.f; sw[j] = 0.f; }
+    __syncthreads();
+    for (int64_t r0 = 0; r0 < n; r0 += 256) {
+        const int64_t row = r0 + tid;
+        float pre[kMergeJ];
+#pragma unroll
+        for (int j = 0; j < kMergeJ; ++j) pre[j] = bj[j];
+        if (row < n) {
+            // these loops are chains of global-load latencies unless the loads are batched: eight float4 of the row in flight at a time
+            constexpr int LB = 8;
+            for (int k0 = 0; k0 < K; k0 += 4 * LB) {
+                mf4 cq[LB];
+#pragma unroll
+                for (int u = 0; u < LB; ++u) {
+                    const int k = k0 + 4 * u;
+                    cq[u] = k >= K ? mf4{0.f, 0.f, 0.f, 0.f} : (k < dim ? *reinterpret_cast<const mf4*>(a + row * dim + k) : *reinterpret_cast<const mf4*>(b + row * dim + (k - dim)));
+                }
+#pragma unroll
+                for (int u = 0; u < LB; ++u) {
+                    const int k = k0 + 4 * u;
+                    if (k < K) {
+#pragma unroll
+                        for (int j = 0; j < kMergeJ; ++j) {
+                            const mf4 wv = *reinterpret_cast<const mf4*>(wj + j * K + k);
+                            pre[j] = fmaf(wv.x, cq[u].x, fmaf(wv.y, cq[u].y, fmaf(wv.z, cq[u].z, fmaf(wv.w, cq[u].w, pre[j]))));
+                        }
+                    }
+                }
+            }
+        }
+        const float g = row < n ? gz[row] : 0.f;
+        sg += g;
+#pragma unroll
+        for (int j = 0; j < kMergeJ; ++j) {
+            const float d = pre[j] > 0.f ? g * vj[j] : 0.f;
+            dhs[tid * kMergeJ + j] = d;
+            if (row < n && j0 + j < hidden) dh[row * hidden + j0 + j] = d;
+            sb[j] += d; sw[j] = fmaf(fmaxf(pre[j], 0.f), g, sw[j]);
+        }
+        __syncthreads();
+        const int nr = n - r0 < 256 ? (int)(n - r0) : 256;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k = tid + 256 * q;
+            if (k < K) {
+                const float* src = k < dim ? a + r0 * dim + k : b + r0 * dim + (k - dim);
+                constexpr int RB = 16;
+                for (int rb = 0; rb < nr; rb += RB) {
+                    float cq[RB];
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) cq[u] = rb + u < nr ? src[(size_t)(rb + u) * dim] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        const int r = rb + u < nr ? rb + u : 0;          // beyond the block: cq = 0
+                        const float cv = cq[u];
+                        const mf4 d0 = *reinterpret_cast<const mf4*>(dhs + r * kMergeJ), d1 = *reinterpret_cast<const mf4*>(dhs + r * kMergeJ + 4);
+                        accw[q][0] = fmaf(d0.x, cv, accw[q][0]); accw[q][1] = fmaf(d0.y, cv, accw[q][1]); accw[q][2] = fmaf(d0.z, cv, accw[q][2]); accw[q][3] = fmaf(d0.w, cv, accw[q][3]);
+                        accw[q][4] = fmaf(d1.x, cv, accw[q][4]); accw[q][5] = fmaf(d1.y, cv, accw[q][5]); accw[q][6] = fmaf(d1.z, cv, accw[q][6]); accw[q][7] = fmaf(d1.w, cv, accw[q][7]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int k = tid + 256 * q;
+        if (k < K)
+#pragma unroll
+            for (int j = 0; j < kMergeJ; ++j)
+                if (j0 + j < hidden) dw1[(size_t)(j0 + j) * K + k] = accw[q][j];
+    }
+#pragma unroll
+    for (int j = 0; j < kMergeJ; ++j) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sb[j] += __shfl_xor(sb[j], o, 64); sw[j] += __shfl_xor(sw[j], o, 64); }
+        if (lane == 0) { red[(wave * 2 + 0) * kMergeJ + j] = sb[j]; red[(wave * 2 + 1) * kMergeJ + j] = sw[j]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sg += __shfl_xor(sg, o, 64);
+    if (lane == 0) red[8 * kMergeJ + wave] = sg;
+    __syncthreads();
+    if (tid < 2 * kMergeJ) {
+        const int which = tid / kMergeJ, j = tid % kMergeJ;
+        const float t = (red[(0 * 2 + which) * kMergeJ + j] + red[(1 * 2 + which) * kMergeJ + j]) + (red[(2 * 2 + which) * kMergeJ + j] + red[(3 * 2 + which) * kMergeJ + j]);
+        if (j0 + j < hidden) (which ? dw2 : db1)[j0 + j] = t;
+    }
+    if (blockIdx.x == 0 && tid == 0) db2[0] = (red[8 * kMergeJ] + red[8 * kMergeJ + 1]) + (red[8 * kMergeJ + 2] + red[8 * kMergeJ + 3]);
+}
+__global__ __launch_bounds__(256) void k_merge_bwd_x(int64_t n, int dim, int hidden, const float* __restrict__ w1, const float* __restrict__ dh,
+                                                      float* __restrict__ da, float* __restrict__ db) {
+    extern __shared__ __attribute__((aligned(16))) float msm[];      // dh rows [8][hidden]
+    const int K = 2 * dim, tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * kMergeRows;
+    for (int idx = tid; idx < kMergeRows * hidden; idx += 256) {
+        const int r = idx / hidden;
+        msm[idx] = row0 + r < n ? dh[(row0 + r) * hidden + (idx - r * hidden)] : 0.f;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+        float acc[kMergeRows];
+#pragma unroll
+        for (int r = 0; r < kMergeRows; ++r) acc[r] = 0.f;
+        constexpr int JB = 16;               // fc1 values in flight per thread
+        for (int j0 = 0; j0 < hidden; j0 += JB) {
+            float wq[JB];
+#pragma unroll
+            for (int u = 0; u < JB; ++u) wq[u] = j0 + u < hidden ? w1[(size_t)(j0 + u) * K + k] : 0.f;
+#pragma unroll
+            for (int u = 0; u < JB; ++u) {
+                const int j = j0 + u < hidden ? j0 + u : 0;
+#pragma unroll
+                for (int r = 0; r < kMergeRows; ++r) acc[r] = fmaf(msm[r * hidden + j], wq[u], acc[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kMergeRows; ++r) {
+            const int64_t row = row0 + r;
+            if (row < n) { if (k < dim) da[row * dim + k] = acc[r]; else db[row * dim + (k - dim)] = acc[r]; }
+        }
+    }
 }
 
 }  // namespace dygnn
@@ -264,28 +424,57 @@ extern "C" int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg, const 
               static_cast<char*>(workspace), wl, taps, as_stream(stream));
 }
 
-extern "C" int dygnn_merge_layer_sigmoid(const float* a, const float* b, int64_t n, int32_t dim, int32_t hidden,
-                                         const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
-                                         float* out, dygnn_stream_t stream) {
+static int merge_forward(const float* a, const float* b, int64_t n, int32_t dim, int32_t hidden, const float* fc1_w, const float* fc1_b, const float* fc2_w,
+                         const float* fc2_b, float* out, int sig, dygnn_stream_t stream) {
     DYGNN_REQUIRE(n >= 0 && dim > 0 && hidden > 0, "merge_layer: bad sizes");
     DYGNN_REQUIRE(n == 0 || (a && b && fc1_w && fc1_b && fc2_w && fc2_b && out), "merge_layer: null pointer");
     if (n == 0) return DYGNN_OK;
     if (dim % 4 == 0 && n >= 2048) {        // few rows: the one-workgroup-per-row kernel below has the shorter critical path
         hipLaunchKernelGGL(k_merge_sigmoid_mfma, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, as_stream(stream), a, b, n, dim, hidden,
-                           fc1_w, fc1_b, fc2_w, fc2_b, out);
+                           fc1_w, fc1_b, fc2_w, fc2_b, out, sig);
         DYGNN_LAUNCH_CHECK();
         return DYGNN_OK;
     }
     if (dim % 4 == 0 && hidden <= 192 && n >= 64) {     // an evaluation step's worth of rows
         hipLaunchKernelGGL(k_merge_sigmoid_mid, dim3((unsigned)ceil_div(n, 16)), dim3(256), 0, as_stream(stream), a, b, n, dim, hidden,
-                           fc1_w, fc1_b, fc2_w, fc2_b, out);
+                           fc1_w, fc1_b, fc2_w, fc2_b, out, sig);
         DYGNN_LAUNCH_CHECK();
         return DYGNN_OK;
     }
     const size_t lds = (size_t)(2 * dim + 4) * sizeof(float);
     DYGNN_REQUIRE(lds <= 64 * 1024, "merge_layer: dim too large");
     hipLaunchKernelGGL(k_merge_sigmoid, dim3((unsigned)n), dim3(256), lds, as_stream(stream), a, b, dim, hidden, fc1_w, fc1_b, fc2_w,
-                       fc2_b, out);
+                       fc2_b, out, sig);
+    DYGNN_LAUNCH_CHECK();
+    return DYGNN_OK;
+}
+
+extern "C" int dygnn_merge_layer_sigmoid(const float* a, const float* b, int64_t n, int32_t dim, int32_t hidden,
+                                         const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
+                                         float* out, dygnn_stream_t stream) {
+    return merge_forward(a, b, n, dim, hidden, fc1_w, fc1_b, fc2_w, fc2_b, out, 1, stream);
+}
+
+extern "C" int dygnn_merge_layer_logits(const float* a, const float* b, int64_t n, int32_t dim, int32_t hidden,
+                                        const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
+                                        float* out, dygnn_stream_t stream) {
+    return merge_forward(a, b, n, dim, hidden, fc1_w, fc1_b, fc2_w, fc2_b, out, 0, stream);
+}
+
+extern "C" int dygnn_merge_layer_backward(const float* a, const float* b, int64_t n, int32_t dim, int32_t hidden, const float* fc1_w, const float* fc1_b,
+                                          const float* fc2_w, const float* grad_logits, float* grad_a, float* grad_b, float* grad_fc1_w, float* grad_fc1_b,
+                                          float* grad_fc2_w, float* grad_fc2_b, float* workspace, dygnn_stream_t stream) {
+    DYGNN_REQUIRE(n >= 0 && dim > 0 && hidden > 0 && dim % 4 == 0 && 2 * dim <= 512, "merge_layer_backward: bad sizes (dim: a multiple of 4, at most 256)");
+    DYGNN_REQUIRE(a && b && fc1_w && fc1_b && fc2_w && grad_logits && grad_a && grad_b && grad_fc1_w && grad_fc1_b && grad_fc2_w && grad_fc2_b && workspace,
+                  "merge_layer_backward: null pointer");
+    const size_t lds_w = (size_t)(kMergeJ * 2 * dim + 256 * kMergeJ + 8 * kMergeJ + 4) * sizeof(float), lds_x = (size_t)kMergeRows * hidden * sizeof(float);
+    DYGNN_REQUIRE(lds_w <= 64 * 1024 && lds_x <= 64 * 1024, "merge_layer_backward: dim / hidden too large");
+    hipLaunchKernelGGL(k_merge_bwd_w, dim3((unsigned)ceil_div(hidden, kMergeJ)), dim3(256), lds_w, as_stream(stream), a, b, n, dim, hidden, fc1_w, fc1_b, fc2_w,
+                       grad_logits, workspace, grad_fc1_w, grad_fc1_b, grad_fc2_w, grad_fc2_b);
+    DYGNN_LAUNCH_CHECK();
+    if (n == 0) return DYGNN_OK;
+    hipLaunchKernelGGL(k_merge_bwd_x, dim3((unsigned)ceil_div(n, (int64_t)kMergeRows)), dim3(256), lds_x, as_stream(stream), n, dim, hidden, fc1_w, workspace, grad_a,
+                       grad_b);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }

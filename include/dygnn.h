@@ -326,6 +326,17 @@ int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg_host, const dygnn
 int dygnn_merge_layer_sigmoid(const float* a, const float* b, int64_t n, int32_t dim, int32_t hidden,
                               const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
                               float* out, dygnn_stream_t stream);
+/* The same head for the TRAINING step (train_link_prediction.py:241-257): the logits z = MergeLayer(a, b) [n] (output_dim 1) and their
+ * backward pass.  grad_logits = dL/dz [n]; grad_a, grad_b [n,dim] and the four parameter gradients are WRITTEN (no accumulation, no
+ * atomics: bitwise reproducible); `workspace` = n * hidden floats.  dim must be a multiple of 4, at most 256. */
+int dygnn_merge_layer_logits(const float* a, const float* b, int64_t n, int32_t dim, int32_t hidden,
+                             const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
+                             float* out, dygnn_stream_t stream);
+int dygnn_merge_layer_backward(const float* a, const float* b, int64_t n, int32_t dim, int32_t hidden,
+                               const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* grad_logits,
+                               float* grad_a, float* grad_b, float* grad_fc1_w, float* grad_fc1_b, float* grad_fc2_w, float* grad_fc2_b,
+                               float* workspace, dygnn_stream_t stream);
+
 
 /* Evaluation metrics on the device, replacing the scikit-learn host round trip of
  * get_link_prediction_metrics / get_node_classification_metrics (utils/metrics.py:5-34; called per batch at

@@ -178,3 +178,30 @@ def test_many_in_training_equals_separate_calls(name, equal_lengths):
         ref = want[k]
         tol = TOL * max(1.0, float(ref.abs().max()))
         assert float((p.grad - ref).abs().max()) <= tol, k
+
+
+@pytest.mark.parametrize("n", [1, 37, 200, 400])
+def test_merge_layer_autograd_matches_the_cpu_module(n):
+    """MergeLayer.forward on the GPU = dygnn_merge_layer_logits / dygnn_merge_layer_backward (models/modules.py:57-68 with its
+    autograd): logits, input gradients and the four parameter gradients against the same module evaluated by PyTorch on the CPU in float64."""
+    from dyglib_amd import MergeLayer, synthetic as syn
+    mp = syn.make_merge_layer_params(7)
+    ref = MergeLayer(172, 172, 172, 1).double()
+    ref.load_state_dict({k: torch.from_numpy(v).double() for k, v in mp.items()})
+    hip = MergeLayer(172, 172, 172, 1)
+    hip.load_state_dict({k: torch.from_numpy(v) for k, v in mp.items()})
+    hip = hip.cuda()
+    rs = np.random.RandomState(n)
+    a, b, g = rs.standard_normal((n, 172)).astype(np.float32), rs.standard_normal((n, 172)).astype(np.float32), rs.standard_normal((n, 1)).astype(np.float32)
+    ar, br = torch.from_numpy(a).double().requires_grad_(True), torch.from_numpy(b).double().requires_grad_(True)
+    zr = ref(ar, br)
+    (zr * torch.from_numpy(g).double()).sum().backward()
+    ah, bh = torch.from_numpy(a).cuda().requires_grad_(True), torch.from_numpy(b).cuda().requires_grad_(True)
+    zh = hip(ah, bh)
+    assert zh.shape == (n, 1) and zh.requires_grad
+    (zh * torch.from_numpy(g).cuda()).sum().backward()
+    close(zh.detach().cpu().numpy(), zr.detach().numpy().astype(np.float32), f"merge logits n={n}", label="MergeLayer logits (HIP autograd path)")
+    close(ah.grad.cpu().numpy(), ar.grad.numpy().astype(np.float32), f"merge d input_1 n={n}", label="MergeLayer input gradients")
+    close(bh.grad.cpu().numpy(), br.grad.numpy().astype(np.float32), f"merge d input_2 n={n}", label="MergeLayer input gradients")
+    for (k, ph), (_, pr) in zip(hip.named_parameters(), ref.named_parameters()):
+        close_scaled(ph.grad.cpu().numpy(), pr.grad.numpy().astype(np.float32), f"merge grad {k} n={n}", label="MergeLayer parameter gradients (scaled bar)")
