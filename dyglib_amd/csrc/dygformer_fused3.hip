@@ -1248,6 +1248,344 @@ __global__ __launch_bounds__(512, 2) void k_ffn_bwd(const FfnBwdArgs a) {
 }
 
 // ================================================================================================
+// Backward of one encoder layer's attention block (DyGFormer.py:440-456 reversed; nn.MultiheadAttention with dropout on the probabilities),
+// token-owner like the forward: a workgroup = 8 waves = NP pairs x TPW token tiles, wave = 16 tokens x all channels.
+// In: dX = d loss / d x1 [M][200] (after k_ffn_bwd).  dAo = dX o mask1 is written as rows (the out-projection's weight-gradient operand) and,
+// per head h, streamed through the layer's backward ring:
+//     dOa^T = Wo[:, h]^T . dAo^T                                                                    (same shape as a Q/K/V product)
+//     phase A, this wave's tokens as QUERIES (K, V of the pair in LDS):  dPd^T = V . dOa^T,  dS^T = P^T o (dPd^T o mask0 - D),  dQ^T = K^T . dS^T
+//     phase B, this wave's tokens as KEYS (Q, dOa of the pair in LDS over K, V):  dPd = dOa . V^T,  dS = P o (dPd o mask0 - D),
+//              dV^T = dOa^T . Pd,  dK^T = Q^T . dS            — tiles [query rows][own key columns] are again MFMA B operands, so the sums over
+//              the pair's queries need no cross-wave exchange beyond D (one float per query, through LDS); P and Pd are re-read from the
+//              forward's [B H][T][T] buffers in either orientation
+//     dxn0^T += Wq[h]^T . dQ^T + Wv[h]^T . dV^T + Wk[h]^T . dK^T                                     (same shape as the out-projection)
+// then LayerNorm-0 backward, dX <- dX + LN0'(dxn0) in place = d loss / d x_l.  dQ | dK | dV leave as rows [M][600] for the grouped
+// weight-gradient launch.  scale = 1/sqrt(head dim) multiplies dS once (it serves both dQ and dK: S = scale q.k).
+template <int TPW>
+__device__ __forceinline__ void s_like(f4 (&sa)[TPW], const float* base, const f4 (&q)[7], int c, int g) {       // sa[kt] += rows(16 kt ..)(base) . q   (forward: S^T = K Q^T)
+    const float q6 = F3_KSKIP ? kpack4(q[6]) : 0.f;
+#pragma unroll
+    for (int kh = 0; kh < TPW / 4; ++kh) {
+        const float* kbase = base + (64 * kh + c) * kKV + 4 * g;
+        f4 kf[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) kf[0][kt] = lds4(kbase + 16 * kt * kKV);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            if (j + 1 < 6 || (!F3_KSKIP && j + 1 < 7)) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) kf[(j + 1) & 1][kt] = lds4(kbase + 16 * kt * kKV + 16 * (j + 1));
+            } else if (j + 1 == 6) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) kf[0][kt].x = kbase[16 * kt * kKV + 96 - 3 * g];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (F3_KSKIP && j == 6) mma_group1<4>(&sa[4 * kh], kf[0], q6); else mma_group<4>(&sa[4 * kh], kf[j & 1], q[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+template <int TPW>
+__device__ __forceinline__ void pv_like(f4 (&oa)[7], const float* base, const f4 (&p)[TPW], int c, int g) {     // oa += rows(base)^T . p   (forward: O^T = V^T P^T)
+    auto load_v = [&](f4 (&va)[4], int kt, int j0, int n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < n) {
+                const float* vp = base + (16 * kt + 4 * g) * kKV + 16 * (j0 + j) + c;
+                va[j].x = vp[0]; va[j].y = vp[kKV]; va[j].z = vp[2 * kKV]; va[j].w = vp[3 * kKV];
+            }
+        }
+    };
+    f4 va[2][4];
+    load_v(va[0], 0, 0, 4);
+#pragma unroll
+    for (int st = 0; st < 2 * TPW; ++st) {
+        const int kt = st >> 1, half = st & 1;
+        if (st + 1 < 2 * TPW) load_v(va[(st + 1) & 1], (st + 1) >> 1, ((st + 1) & 1) ? 4 : 0, ((st + 1) & 1) ? 3 : 4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (half == 0) mma_group<4>(&oa[0], va[st & 1], p[kt]); else mma_group<3>(&oa[4], va[st & 1], p[kt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// acc (13 model-dim tiles) += W^T(7 d-chunks x 13 tiles, from the ring) . t (7 head-dim tiles)   (forward: the out-projection)
+__device__ __forceinline__ void proj_t(f4 (&acc)[kNT], const f4 (&t)[7], WStream& ws, const float* ringl, bool active) {
+    ws.fit(13);
+    f4 fs[2][4];
+    float t6 = 0.f;
+    if (active) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) fs[0][v] = lds4(ringl + (ws.pos + v) * kFrag);
+        if (F3_KSKIP) t6 = kpack4(t[6]);
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int pcur = ws.pos;
+        const int pnext = ws.next_pos(13, 13);
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gi = 4 * j + q;
+                const int i0 = q == 0 ? 0 : 4 + 3 * (q - 1), n = q == 0 ? 4 : 3;
+                if (q + 1 < 4) {
+                    const int j0 = 4 + 3 * q;
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) fs[(gi + 1) & 1][v] = lds4(ringl + (pcur + j0 + v) * kFrag);
+                } else if (j + 1 < 7) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) fs[(gi + 1) & 1][v] = lds4(ringl + (pnext + v) * kFrag);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (F3_KSKIP && j == 6) { if (n == 4) mma_group1<4>(&acc[i0], fs[gi & 1], t6); else mma_group1<3>(&acc[i0], fs[gi & 1], t6); }
+                else if (n == 4) mma_group<4>(&acc[i0], fs[gi & 1], t[j]); else mma_group<3>(&acc[i0], fs[gi & 1], t[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        ws.advance(13);
+        if (j + 1 < 7) ws.fit(13);
+    }
+}
+// LayerNorm backward of a token-owner wave against stored statistics (shared by the two backward kernels): dX rows += rstd (gy - mean(gy) -
+// xhat mean(gy xhat)), gy = dxn gamma; the workgroup's sums of dxn xhat / dxn over its tokens go to `red` [8 waves][2][208]
+__device__ __forceinline__ void ln_backward(const f4 (&dxn)[kNT], const float* xrows, const float* mean_p, const float* rstd_p, const float* gam, float* dXrows,
+                                            int64_t row, bool valid, float* red, int wave, int c, int g) {
+    const float mean = valid ? mean_p[row] : 0.f, rstd = valid ? rstd_p[row] : 0.f;
+    const float* xr = xrows + row * kD + 4 * g;
+    f4 xh[kNT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) {
+        const bool on = valid && (i < 12 || g < 2);
+        const f4 xv = on ? ldg4(xr + 16 * i) : zero4();
+        const f4 gm = lds4(gam + 16 * i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xh[i][r] = on ? (xv[r] - mean) * rstd : 0.f;
+            const float gy = dxn[i][r] * gm[r];
+            s1 += gy; s2 = fmaf(gy, xh[i][r], s2);
+        }
+    }
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+    const float m1v = s1 * (1.0f / kD), m2v = s2 * (1.0f / kD);
+    float* dxr = dXrows + row * kD + 4 * g;
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) {
+        const bool on = valid && (i < 12 || g < 2);
+        const f4 gm = lds4(gam + 16 * i);
+        f4 pg, pb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pg[r] = row_sum16(dxn[i][r] * xh[i][r]);
+            pb[r] = row_sum16(dxn[i][r]);
+        }
+        if (c == 0) {
+            *reinterpret_cast<f4*>(red + (wave * 2 + 0) * kDP + 16 * i + 4 * g) = pg;
+            *reinterpret_cast<f4*>(red + (wave * 2 + 1) * kDP + 16 * i + 4 * g) = pb;
+        }
+        if (on) {
+            f4 v = ldg4(dxr + 16 * i);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rstd * (dxn[i][r] * gm[r] - m1v - xh[i][r] * m2v);
+            *reinterpret_cast<f4*>(dxr + 16 * i) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+struct AttnBwdArgs {
+    const float* stream; int nstages;
+    int64_t B; int T;
+    float* dX;                                   // [M][200] in: d x1; out: d x_l
+    const float *X, *m0, *r0;                    // layer input rows and LN0 statistics
+    const float *qkv, *P, *Pd;                   // forward activations
+    float *dAo, *dQKV;                           // [M][200], [M][600]
+    float *dgamma, *dbeta;                       // LN0 (accumulated)
+    train::Drop dr; uint32_t site_p, site_ao;
+    float qscale;
+};
+template <int TPW>
+__global__ __launch_bounds__(512, 2) void k_attn_bwd(const AttnBwdArgs a) {
+    constexpr int NP = 8 / TPW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pi = wave / TPW, tt = wave % TPW;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t b = (int64_t)blockIdx.x * NP + pi;
+    const int T = a.T;
+    const bool pair_ok = b < a.B;
+    const bool active = pair_ok && 16 * tt < T, valid = pair_ok && 16 * tt + c < T;
+    const int tok = 16 * tt + c;
+    const int64_t row = b * T + tok;
+    const int tokbase = pi * (16 * TPW);
+    WStream ws;
+    ws.open(a.stream, kLdsRing, lane, wave, a.nstages);
+    const float* ringl = lds + kLdsRing + lane * 4;
+    float* Kb = lds + kLdsK;
+    float* Vb = lds + kLdsV;
+    float* Dq = lds + kLdsMisc;                  // [128] D of every query of the workgroup
+    for (int i = tid; i < kLdsRing / 4; i += 512) reinterpret_cast<f4*>(lds)[i] = zero4();      // rows of absent tokens are MFMA operands: finite
+    if (tid < kTokWG) Dq[tid] = 0.f;
+    // dAo = dX o mask1 (DyGFormer.py:456), as rows: the operand of the out-projection's weight gradient and of the dOa products below
+    {
+        const uint32_t sk = a.dr.site_key(a.site_ao), e0 = (uint32_t)row * kD + 4 * g;
+        const float* src = a.dX + row * kD + 4 * g;
+        float* dst = a.dAo + row * kD + 4 * g;
+#pragma unroll
+        for (int i = 0; i < kNT; ++i) {
+            if (valid && (i < 12 || g < 2)) {
+                f4 v = ldg4(src + 16 * i);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= a.dr.mask32(sk, e0 + 16 * i + r);
+                *reinterpret_cast<f4*>(dst + 16 * i) = v;
+            }
+        }
+    }
+    f4 dxn[kNT];
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) dxn[i] = zero4();
+    const uint32_t skp = a.dr.site_key(a.site_p);
+    const bool vec = (T & 3) == 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the first ring stages have landed (and this lane's dAo row is written)
+    __syncthreads();
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        const float* qrow = a.qkv + row * (3 * kD) + kHD * h + 4 * g;
+        float* drow = a.dQKV + row * (3 * kD) + kHD * h + 4 * g;
+        const int64_t pbase = (b * 2 + h) * (int64_t)T * T;
+        // ---- dOa^T = Wo[:, h]^T . dAo^T
+        f4 doa[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) doa[j] = zero4();
+        {
+            f4 dA[kNT];
+            load_rows(dA, a.dAo, row, g, valid);
+            float k0 = 0.f, k1 = 0.f;
+            if (F3_KSKIP) kpack(dA[kKC - 1], k0, k1);
+            qkv_group(doa, dA, k0, k1, ws, ringl, active);
+        }
+        // ---- K, V rows of this wave's tokens into LDS (every wave passed stream barriers since the previous head's last reads), Q^T scaled
+        f4 qa[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const bool on = valid && (j < 6 || g == 0);
+            qa[j] = on ? ldg4(qrow + 16 * j) * a.qscale : zero4();
+            if (active && (j < 6 || g == 0)) {
+                *reinterpret_cast<f4*>(Kb + (tokbase + tok) * kKV + 4 * g + 16 * j) = on ? ldg4(qrow + kD + 16 * j) : zero4();
+                *reinterpret_cast<f4*>(Vb + (tokbase + tok) * kKV + 4 * g + 16 * j) = on ? ldg4(qrow + 2 * kD + 16 * j) : zero4();
+            }
+        }
+        __syncthreads();
+        // ---- phase A: this wave's tokens as queries
+        f4 dq[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) dq[j] = zero4();
+        if (active) {
+            f4 ds[TPW], pt[TPW];
+#pragma unroll
+            for (int kt = 0; kt < TPW; ++kt) ds[kt] = zero4();
+            s_like<TPW>(ds, Vb + tokbase * kKV, doa, c, g);                    // dPd^T[key][query]
+            const float* Pq = a.P + pbase + (int64_t)tok * T;
+            float D = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < TPW; ++kt) {
+                const int key0 = 16 * kt + 4 * g;
+                if (vec) pt[kt] = (valid && key0 < T) ? ldg4(Pq + key0) : zero4();
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pt[kt][r] = (valid && key0 + r < T) ? Pq[key0 + r] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ds[kt][r] *= a.dr.mask32(skp, (uint32_t)(pbase + (int64_t)tok * T) + key0 + r);       // dP = dPd o mask0
+                    D = fmaf(ds[kt][r], pt[kt][r], D);
+                }
+            }
+            D += __shfl_xor(D, 16, 64);
+            D += __shfl_xor(D, 32, 64);
+#pragma unroll
+            for (int kt = 0; kt < TPW; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ds[kt][r] = pt[kt][r] * (ds[kt][r] - D) * a.qscale;
+            if (g == 0) Dq[tokbase + tok] = D;
+            pv_like<TPW>(dq, Kb + tokbase * kKV, ds, c, g);                    // dQ^T = K^T . dS^T (scaled)
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+                    if (j < 6 || g == 0) *reinterpret_cast<f4*>(drow + 16 * j) = dq[j];
+            }
+        }
+        __syncthreads();                             // every wave is done with K and V
+        // ---- Q (unscaled) and dOa rows over K and V; this wave's V^T tiles (its tokens as keys)
+        f4 vt[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const bool on = valid && (j < 6 || g == 0);
+            vt[j] = on ? ldg4(qrow + 2 * kD + 16 * j) : zero4();
+            if (active && (j < 6 || g == 0)) {
+                *reinterpret_cast<f4*>(Kb + (tokbase + tok) * kKV + 4 * g + 16 * j) = on ? ldg4(qrow + 16 * j) : zero4();
+                *reinterpret_cast<f4*>(Vb + (tokbase + tok) * kKV + 4 * g + 16 * j) = doa[j];
+            }
+        }
+        __syncthreads();
+        // dxn0 += Wq[h]^T . dQ^T while the exchange settles (stream order: Wo^T, Wq^T, Wv^T, Wk^T)
+        proj_t(dxn, dq, ws, ringl, active);
+        // ---- phase B: this wave's tokens as keys; tiles [query rows 16 qt + 4 g + r][own key column c]
+        f4 dv[7], dk[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { dv[j] = zero4(); dk[j] = zero4(); }
+        {
+            f4 ds2[TPW], pd2[TPW];
+#pragma unroll
+            for (int qt = 0; qt < TPW; ++qt) { ds2[qt] = zero4(); pd2[qt] = zero4(); }
+            if (active) {
+                s_like<TPW>(ds2, Vb + tokbase * kKV, vt, c, g);                // dPd[query][key] = dOa[query] . V[key]
+#pragma unroll
+                for (int qt = 0; qt < TPW; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = 16 * qt + 4 * g + r;
+                        const bool on = valid && q < T;
+                        const int64_t off = pbase + (int64_t)q * T + tok;
+                        const float pv = on ? a.P[off] : 0.f;
+                        pd2[qt][r] = on ? a.Pd[off] : 0.f;
+                        const float dp = ds2[qt][r] * a.dr.mask32(skp, (uint32_t)off);
+                        ds2[qt][r] = pv * (dp - Dq[tokbase + q]) * a.qscale;
+                    }
+                pv_like<TPW>(dv, Vb + tokbase * kKV, pd2, c, g);               // dV^T = dOa^T . Pd
+                if (valid) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j)
+                        if (j < 6 || g == 0) *reinterpret_cast<f4*>(drow + 2 * kD + 16 * j) = dv[j];
+                }
+            }
+            proj_t(dxn, dv, ws, ringl, active);
+            if (active) {
+                pv_like<TPW>(dk, Kb + tokbase * kKV, ds2, c, g);               // dK^T = Q^T . dS (scaled)
+                if (valid) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j)
+                        if (j < 6 || g == 0) *reinterpret_cast<f4*>(drow + kD + 16 * j) = dk[j];
+                }
+            }
+        }
+        proj_t(dxn, dk, ws, ringl, active);
+    }
+    // ---- LayerNorm-0 backward
+    ws.fit(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                 // every wave is done with the K/V region: it now holds the dgamma / dbeta partial sums
+    ln_backward(dxn, a.X, a.m0, a.r0, lds + kLdsRing + ws.pos * kFrag + 4 * g, a.dX, row, valid, lds, wave, c, g);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = tid; i < 2 * kDP; i += 512) {
+        const int which = i / kDP, n = i % kDP;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += lds[(w * 2 + which) * kDP + n];
+        if (n < kD) atomicAdd((which ? a.dbeta : a.dgamma) + n, t);
+    }
+}
+
+// ================================================================================================
 // packing: the stream is described on the host as a list of fragment descriptors in consumption order (with the pad
 // fragments the ring rule asks for), uploaded, and materialised by one kernel.
 // ================================================================================================
@@ -1354,6 +1692,37 @@ static void build_bwd_ffn(const dygnn_encoder_layer_weights& L, StreamBuilder& s
     sb.put_vec(L.norm1_weight, 0, kD);
 }
 constexpr int64_t kBwdFfnFrags = 25 * 52 + 1;
+// backward stream of layer l's attention block (k_attn_bwd): per head Wo[:, h]^T in the shape of a Q/K/V product ([channel chunk][7 head-dim
+// tiles]), then Wq[h]^T, Wv[h]^T, Wk[h]^T in the shape of the out-projection ([head-dim chunk][13 channel tiles]); then LN0's gamma
+static void build_bwd_attn(const dygnn_encoder_layer_weights& L, StreamBuilder& sb) {
+    for (int h = 0; h < 2; ++h) {
+        sb.fit(7);
+        for (int kc = 0; kc < kKC; ++kc) {
+            for (int j = 0; j < 7; ++j)
+                sb.put(L.out_proj_weight, kD, kHD * h + 16 * j, kHD * (h + 1), 16 * kc, kD, ((F3_KSKIP && kc == kKC - 1) ? 1 : 0) | 4);
+            if (kc + 1 < kKC) sb.fit(7);
+        }
+        const int order[3] = {0, 2, 1};              // q, v, k
+        for (int o = 0; o < 3; ++o) {
+            const float* Wp = L.in_proj_weight ? L.in_proj_weight + (size_t)order[o] * kD * kD : nullptr;
+            sb.fit(13);
+            for (int j = 0; j < 7; ++j) {
+                for (int i = 0; i < kNT; ++i) sb.put(Wp, kD, 16 * i, kD, kHD * h + 16 * j, kHD * (h + 1), ((F3_KSKIP && j == 6) ? 2 : 0) | 4);
+                if (j + 1 < 7) sb.fit(13);
+            }
+        }
+    }
+    sb.fit(1);
+    sb.put_vec(L.norm0_weight, 0, kD);
+}
+static int64_t bwd_attn_frags() {
+    static float dummy;
+    dygnn_encoder_layer_weights lw{};
+    lw.in_proj_weight = lw.out_proj_weight = lw.norm0_weight = &dummy;
+    StreamBuilder sb;
+    build_bwd_attn(lw, sb);
+    return (int64_t)sb.frags.size();
+}
 
 // projection fragments in step order (channels node, time, edge, cooc; 4 tiles per k-chunk), staged by slabs
 static void build_proj(const Dims& d, const dygnn_dygformer_weights* w, StreamBuilder& sb) {
@@ -1382,6 +1751,7 @@ struct PackLayout3 {       // float offsets relative to PackedLayout.fused3
     int scr_floats, slab_chunks;                   // LDS split of the K/V region during the prologue
     int np, slab_in_ring;                          // pairs per workgroup (0: shape unsupported); slab placed in the weight ring
     size_t bwd[DYGNN_MAX_LAYERS]; int bwd_nstages;  // per layer: the backward stream of its FFN block (training only)
+    size_t bwa[DYGNN_MAX_LAYERS]; int bwa_nstages; int64_t bwa_frags;      // ... and of its attention block
     size_t desc;           // FragDesc table (device copy), 8-byte aligned
     size_t total;
 };
@@ -1417,7 +1787,10 @@ static PackLayout3 make_layout3(const Dims& d) {
     f.proj = take((size_t)f.nproj * kFrag);
     f.bwd_nstages = (int)((kBwdFfnFrags + kStage - 1) / kStage);
     for (int l = 0; l < d.NL; ++l) f.bwd[l] = take((size_t)(f.bwd_nstages + 1) * kStage * kFrag);
-    f.desc = take(((size_t)(f.nfrag + f.naux + f.nproj + d.NL * kBwdFfnFrags) * sizeof(FragDesc) + 3) / 4);
+    f.bwa_frags = bwd_attn_frags();
+    f.bwa_nstages = (int)((f.bwa_frags + kStage - 1) / kStage);
+    for (int l = 0; l < d.NL; ++l) f.bwa[l] = take((size_t)(f.bwa_nstages + 1) * kStage * kFrag);
+    f.desc = take(((size_t)(f.nfrag + f.naux + f.nproj + d.NL * (kBwdFfnFrags + f.bwa_frags)) * sizeof(FragDesc) + 3) / 4);
     // prologue LDS split: pairs per workgroup, window arrays (5 x 2 sides x Smax ints per pair), projection slab
     const int per_pair = 5 * 2 * ((d.Smax + 3) & ~3);
     f.np = 0; f.slab_in_ring = 0; f.scr_floats = 0; f.slab_chunks = 0;
@@ -1470,6 +1843,9 @@ int pack(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w
             hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(kBwdFfnFrags * kFrag, 256)), dim3(256), 0, s, dd + f.nfrag + f.naux + f.nproj + l * kBwdFfnFrags,
                                kBwdFfnFrags, base + f.bwd[l]);
             DYGNN_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.bwa_frags * kFrag, 256)), dim3(256), 0, s,
+                               dd + f.nfrag + f.naux + f.nproj + d.NL * kBwdFfnFrags + l * f.bwa_frags, f.bwa_frags, base + f.bwa[l]);
+            DYGNN_LAUNCH_CHECK();
         }
         return DYGNN_OK;
     }
@@ -1501,10 +1877,19 @@ int pack(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w
         if ((int64_t)sbb.frags.size() != kBwdFfnFrags) { set_error("pack: backward stream builder mismatch"); return DYGNN_E_INVALID; }
         bw.insert(bw.end(), sbb.frags.begin(), sbb.frags.end());
     }
+    for (int l = 0; l < d.NL; ++l) {
+        StreamBuilder sba;
+        build_bwd_attn(w->layers[l], sba);
+        if ((int64_t)sba.frags.size() != f.bwa_frags) { set_error("pack: attention backward stream builder mismatch"); return DYGNN_E_INVALID; }
+        bw.insert(bw.end(), sba.frags.begin(), sba.frags.end());
+    }
     FragDesc* bdesc = ddesc + f.nfrag + f.naux + f.nproj;
     DYGNN_HIP(hipMemcpyAsync(bdesc, bw.data(), bw.size() * sizeof(FragDesc), hipMemcpyHostToDevice, s));
     for (int l = 0; l < d.NL; ++l) {
         hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(kBwdFfnFrags * kFrag, 256)), dim3(256), 0, s, bdesc + l * kBwdFfnFrags, kBwdFfnFrags, base + f.bwd[l]);
+        DYGNN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.bwa_frags * kFrag, 256)), dim3(256), 0, s, bdesc + d.NL * kBwdFfnFrags + l * f.bwa_frags, f.bwa_frags,
+                           base + f.bwa[l]);
         DYGNN_LAUNCH_CHECK();
     }
     DYGNN_HIP(hipStreamSynchronize(s));     // the descriptor tables are copied from this call's host vectors
@@ -1589,6 +1974,26 @@ int ffn_backward_fused3(const Dims& d, const PackedLayout& pl, const float* pack
     a.dr = dr; a.site_act = (uint32_t)(4 * l + 2); a.site_out = (uint32_t)(4 * l + 3);
     DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffn_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     hipLaunchKernelGGL(k_ffn_bwd, dim3((unsigned)ceil_div(M, (int64_t)kTokWG)), dim3(512), kLdsBytes, s, a);
+    DYGNN_LAUNCH_CHECK();
+    return DYGNN_OK;
+}
+
+// Attention block of layer l, backward (k_attn_bwd); B pairs of T tokens each (one group: the training path's dense layout)
+int attn_backward_fused3(const Dims& d, const PackedLayout& pl, const float* packed, int l, int64_t B, int T, float* dX, const float* X, const float* m0,
+                         const float* r0, const float* qkv, const float* P, const float* Pd, float* dAo, float* dQKV, float* dgamma, float* dbeta,
+                         const train::Drop& dr, hipStream_t s) {
+    using namespace v3;
+    if (!supported(d) || T > 128) { set_error("fused attention backward: unsupported shape"); return DYGNN_E_UNSUPPORTED; }
+    const PackLayout3 f = make_layout3(d);
+    AttnBwdArgs a{};
+    a.stream = packed + pl.fused3 + f.bwa[l]; a.nstages = f.bwa_nstages;
+    a.B = B; a.T = T; a.dX = dX; a.X = X; a.m0 = m0; a.r0 = r0; a.qkv = qkv; a.P = P; a.Pd = Pd; a.dAo = dAo; a.dQKV = dQKV; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.dr = dr; a.site_p = (uint32_t)(4 * l + 0); a.site_ao = (uint32_t)(4 * l + 1);
+    a.qscale = (float)sqrt(1.0 / (double)d.hd);
+    DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    if (T <= 64) hipLaunchKernelGGL(k_attn_bwd<4>, dim3((unsigned)((B + 1) / 2)), dim3(512), kLdsBytes, s, a);
+    else hipLaunchKernelGGL(k_attn_bwd<8>, dim3((unsigned)B), dim3(512), kLdsBytes, s, a);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }

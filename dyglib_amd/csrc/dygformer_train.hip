@@ -21,6 +21,9 @@ int window_lengths_device(const Dims& d, const dygnn_csr* csr, const int64_t* sr
 namespace train { struct TrainOut; }
 bool fused3_supported(const Dims& d);                                                                   // dygformer_fused3.hip
 namespace train { struct Drop; }
+int attn_backward_fused3(const Dims& d, const PackedLayout& pl, const float* packed, int l, int64_t B, int T, float* dX, const float* X, const float* m0,
+                         const float* r0, const float* qkv, const float* P, const float* Pd, float* dAo, float* dQKV, float* dgamma, float* dbeta,
+                         const train::Drop& dr, hipStream_t s);
 int ffn_backward_fused3(const Dims& d, const PackedLayout& pl, const float* packed, int l, int64_t M, float* dX, const float* hpre, const float* x1,
                         const float* m1, const float* r1, float* dF2, float* dH, float* dgamma, float* dbeta, const train::Drop& dr, hipStream_t s);
 int forward_fused3_train(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, const float* packed, const dygnn_csr* csr,
@@ -1216,11 +1219,16 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
                                dX, G(Lg.norm1_weight), G(Lg.norm1_bias));                                                      // dX is now dX1
             DYGNN_LAUNCH_CHECK();
         }
-        // X1 = Xin + drop(Ao), Ao = Oa Wo^T + bo
-        EW(k_drop_bwd, M * D, dX, M * D, dr, (uint32_t)(4 * l + 1), dAo);                                                      // dAo
+        // X1 = Xin + drop(Ao), Ao = Oa Wo^T + bo ; Oa_bh = Pd_bh V_bh ; S_bh = scale Q_bh K_bh^T ; [Q | K | V] = LN0(Xin) Win^T + bin
         dw.add(dAo, D, D, F32(L.oa), D, D, G(Lg.out_proj_weight), D, G(Lg.out_proj_bias));                                     // dWo [D][D], dbo
+        dw.add(dQKV, 3 * D, 3 * D, F32(L.xn0), D, D, G(Lg.in_proj_weight), D, G(Lg.in_proj_bias));                              // dWin [3D][D], dbin
+        if (fused && T <= 128 && H == 2) {      // the whole block in one kernel (dygformer_fused3.hip: k_attn_bwd): dAo, dQKV written for the grouped launch, dX <- dX_l in place
+            if (int rc = attn_backward_fused3(d, make_packed_layout(d), static_cast<const float*>(packed), l, B, T, dX, F32(p.X[l]), F32(L.m0), F32(L.r0), F32(L.qkv), F32(L.P),
+                                              F32(L.Pd), dAo, dQKV, G(Lg.norm0_weight), G(Lg.norm0_bias), dr, s)) return rc;
+            continue;
+        }
+        EW(k_drop_bwd, M * D, dX, M * D, dr, (uint32_t)(4 * l + 1), dAo);                                                      // dAo
         if (int rc = mm(s, dAo, D, false, Lw.out_proj_weight, D, false, dBf, D, (int)M, D, D)) return rc;                       // dOa
-        // attention: Oa_bh = Pd_bh V_bh ; S_bh = scale Q_bh K_bh^T
         // dV_bh = Pd^T dOa_bh
         if (int rc = mm(s, F32(L.Pd), T, true, dBf, D, false, dQKV + 2 * D, 3 * D, T, hd, T, nullptr, 1.f, 0.f, (int)(B * H), H, (int64_t)H * T * T, (int64_t)T * T,
                         (int64_t)T * D, hd, (int64_t)T * 3 * D, hd)) return rc;
@@ -1234,7 +1242,6 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
                         (int64_t)T * T, (int64_t)T * 3 * D, hd, (int64_t)T * 3 * D, hd)) return rc;
         if (int rc = mm(s, F32(L.S), T, true, F32(L.qkv), 3 * D, false, dQKV + D, 3 * D, T, hd, T, nullptr, scale, 0.f, (int)(B * H), H, (int64_t)H * T * T,
                         (int64_t)T * T, (int64_t)T * 3 * D, hd, (int64_t)T * 3 * D, hd)) return rc;
-        dw.add(dQKV, 3 * D, 3 * D, F32(L.xn0), D, D, G(Lg.in_proj_weight), D, G(Lg.in_proj_bias));                              // dWin [3D][D], dbin
         if (int rc = mm(s, dQKV, 3 * D, false, Lw.in_proj_weight, D, false, dA, D, (int)M, D, 3 * D)) return rc;                // dxn0
         hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)ceil_div(M, 64)), dim3(256), 8 * D * sizeof(float), s, dA, F32(p.X[l]), F32(L.m0), F32(L.r0), Lw.norm0_weight, M, D,
                            dX, G(Lg.norm0_weight), G(Lg.norm0_bias));                                                          // dX is now dX_l
