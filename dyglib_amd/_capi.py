@@ -104,7 +104,7 @@ SIGNATURES = {
     "dygnn_dygformer_pack": (C.c_int, [C.POINTER(DygformerConfig), C.POINTER(DygformerWeights), C.c_void_p, C.c_size_t,
                                        C.c_void_p]),
     "dygnn_dygformer_repack": (C.c_int, [C.POINTER(DygformerConfig), C.POINTER(DygformerWeights), C.c_void_p, C.c_size_t,
-                                         C.c_void_p]),
+                                         C.c_int32, C.c_void_p]),
     "dygnn_dygformer_workspace_bytes": (C.c_size_t, [C.POINTER(DygformerConfig), C.c_int64]),
     "dygnn_dygformer_workspace_bytes_for": (C.c_size_t, [C.POINTER(DygformerConfig), C.c_int64, C.c_int32]),
     "dygnn_dygformer_forward": (C.c_int, [C.POINTER(DygformerConfig), C.POINTER(DygformerWeights), C.c_void_p, C.POINTER(Csr),

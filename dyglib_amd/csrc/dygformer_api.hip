@@ -362,7 +362,8 @@ extern "C" size_t dygnn_dygformer_workspace_bytes_for(const dygnn_dygformer_conf
     return generic ? wl.total : wl.X;
 }
 
-static int pack_impl(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, void* packed, size_t packed_bytes, dygnn_stream_t stream, bool reuse_desc) {
+static int pack_impl(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, void* packed, size_t packed_bytes, dygnn_stream_t stream, bool reuse_desc,
+                     bool fused_only = false) {
     if (int rc = check_config(cfg)) return rc;
     const Dims d = make_dims(*cfg);
     if (int rc = check_weights(d, w)) return rc;
@@ -372,7 +373,8 @@ static int pack_impl(const dygnn_dygformer_config* cfg, const dygnn_dygformer_we
         set_error("pack: buffer too small (%zu < %zu bytes)", packed_bytes, pl.total * sizeof(float));
         return DYGNN_E_WORKSPACE;
     }
-    if (int rc = pack_generic(d, pl, w, static_cast<float*>(packed), as_stream(stream))) return rc;
+    if (!(fused_only && fused3_supported(d)))
+        if (int rc = pack_generic(d, pl, w, static_cast<float*>(packed), as_stream(stream))) return rc;
     if (fused3_supported(d))
         if (int rc = pack_fused3(d, pl, w, static_cast<float*>(packed), as_stream(stream), reuse_desc)) return rc;
     return DYGNN_OK;
@@ -384,8 +386,8 @@ extern "C" int dygnn_dygformer_pack(const dygnn_dygformer_config* cfg, const dyg
 }
 
 extern "C" int dygnn_dygformer_repack(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, void* packed,
-                                      size_t packed_bytes, dygnn_stream_t stream) {
-    return pack_impl(cfg, w, packed, packed_bytes, stream, true);
+                                      size_t packed_bytes, int32_t fused_only, dygnn_stream_t stream) {
+    return pack_impl(cfg, w, packed, packed_bytes, stream, true, fused_only != 0);
 }
 
 extern "C" int dygnn_dygformer_forward(const dygnn_dygformer_config* cfg, const dygnn_dygformer_weights* w, const void* packed,

@@ -1617,6 +1617,37 @@ __global__ void k_pack_stream(const FragDesc* __restrict__ desc, int64_t nfrag, 
     dst[idx] = v;
 }
 
+// every fragment stream of the packed buffer in ONE launch (the in-place refresh after an optimizer step): the descriptor table is one
+// array, `r` maps its ranges to their destinations
+struct PackRanges { int n; int64_t start[4 + 2 * DYGNN_MAX_LAYERS]; float* dst[3 + 2 * DYGNN_MAX_LAYERS]; };
+__global__ void k_pack_ranges(const FragDesc* __restrict__ desc, const PackRanges r) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t f = idx >> 8;
+    if (f >= r.start[r.n]) return;
+    int q = 0;
+    while (q + 1 < r.n && f >= r.start[q + 1]) ++q;
+    const int t = idx & 3, lane = (idx >> 2) & 63;
+    const FragDesc d = desc[f];
+    const int c = lane & 15, g = lane >> 4;
+    const int row = d.r0 + c;
+    int col = d.c0 + 4 * g + t;
+    if ((d.kmode & 3) == 1) col = t < 2 ? d.c0 + (g & 1) * 4 + (g >> 1) + 2 * t : d.cmax;
+    if ((d.kmode & 3) == 2) col = t == 0 ? d.c0 + g : d.cmax;
+    float v = 0.f;
+    if (d.src != nullptr) {
+        if (d.ld < 0) { const int e = (int)(idx & 255); if (e < d.rmax) v = d.src[d.c0 + e]; }
+        else if (row >= 0 && row < d.rmax && col < d.cmax) v = (d.kmode & 4) ? d.src[(size_t)col * d.ld + row] : d.src[(size_t)row * d.ld + col];
+    }
+    r.dst[q][(f - r.start[q]) * kFrag + (idx & 255)] = v;
+}
+// the four projection biases in model-dim order [208]
+__global__ void k_pack_bias4(const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ b3, float* __restrict__ dst) {
+    const int i = threadIdx.x;
+    if (i >= kDP) return;
+    const int ch = i / kC, j = i % kC;
+    dst[i] = i < kD ? (ch == 0 ? b0 : ch == 1 ? b1 : ch == 2 ? b2 : b3)[j] : 0.f;
+}
+
 __global__ void k_pack_vec3(const float* __restrict__ src, int n_valid, int src_off, float* __restrict__ dst, int dst_off, int n_total) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_total) return;
@@ -1828,25 +1859,19 @@ int pack(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w
     const PackLayout3 f = make_layout3(d);
     float* base = packed + pl.fused3;
     if (!reuse_desc) DYGNN_HIP(hipMemsetAsync(base, 0, f.total * sizeof(float), s));
-    const float* pb[4] = {w->proj_node_b, w->proj_edge_b, w->proj_time_b, w->proj_cooc_b};
-    for (int ch = 0; ch < 4; ++ch)
-        if (int rc = pack_vec(pb[ch], kC, 0, base + f.bias_x, kC * ch, kC, s)) return rc;
+    hipLaunchKernelGGL(k_pack_bias4, dim3(1), dim3(256), 0, s, w->proj_node_b, w->proj_edge_b, w->proj_time_b, w->proj_cooc_b, base + f.bias_x);
+    DYGNN_LAUNCH_CHECK();
     if (reuse_desc) {
-        const FragDesc* dd = reinterpret_cast<const FragDesc*>(base + f.desc);
-        hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.nproj * kFrag, 256)), dim3(256), 0, s, dd + f.nfrag + f.naux, f.nproj, base + f.proj);
+        // table order (as laid down by the full pack below): stream | aux | proj | NL x FFN backward | NL x attention backward
+        PackRanges r{};
+        int64_t o = 0;
+        auto range = [&](int64_t nfr, float* dst) { r.start[r.n] = o; r.dst[r.n] = dst; ++r.n; o += nfr; };
+        range(f.nfrag, base + f.stream); range(f.naux, base + f.aux); range(f.nproj, base + f.proj);
+        for (int l = 0; l < d.NL; ++l) range(kBwdFfnFrags, base + f.bwd[l]);
+        for (int l = 0; l < d.NL; ++l) range(f.bwa_frags, base + f.bwa[l]);
+        r.start[r.n] = o;
+        hipLaunchKernelGGL(k_pack_ranges, dim3((unsigned)ceil_div(o * kFrag, 256)), dim3(256), 0, s, reinterpret_cast<const FragDesc*>(base + f.desc), r);
         DYGNN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.nfrag * kFrag, 256)), dim3(256), 0, s, dd, f.nfrag, base + f.stream);
-        DYGNN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.naux * kFrag, 256)), dim3(256), 0, s, dd + f.nfrag, f.naux, base + f.aux);
-        DYGNN_LAUNCH_CHECK();
-        for (int l = 0; l < d.NL; ++l) {
-            hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(kBwdFfnFrags * kFrag, 256)), dim3(256), 0, s, dd + f.nfrag + f.naux + f.nproj + l * kBwdFfnFrags,
-                               kBwdFfnFrags, base + f.bwd[l]);
-            DYGNN_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)ceil_div(f.bwa_frags * kFrag, 256)), dim3(256), 0, s,
-                               dd + f.nfrag + f.naux + f.nproj + d.NL * kBwdFfnFrags + l * f.bwa_frags, f.bwa_frags, base + f.bwa[l]);
-            DYGNN_LAUNCH_CHECK();
-        }
         return DYGNN_OK;
     }
     StreamBuilder sb;

@@ -61,7 +61,7 @@ class _TrainFunction(torch.autograd.Function):
         B = src.numel()
         lib, cfg = model._lib, model._cfg
         # the fused training forward reads the kernel-ready weight copy (refreshed here after an optimizer step, launches only)
-        weights, packed = model._packed_weights(dev)
+        weights, packed = model._packed_weights(dev, training=True)
         nbytes = lib.dygnn_dygformer_train_workspace_bytes(C.byref(cfg), B)
         if nbytes == 0:
             _capi.check(-3)
@@ -78,8 +78,8 @@ class _TrainFunction(torch.autograd.Function):
                                                C.cast(seq, C.c_void_p), packed.data_ptr(), _capi.current_stream_ptr())
         _capi.check(rc)
         ctx.model, ctx.ws, ctx.seq, ctx.B, ctx.dropout_p, ctx.seed = model, ws, seq, B, float(dropout_p), int(seed)
-        ctx.packed = packed
-        ctx.param_versions = [(p.data_ptr(), p._version) for p in model.parameters()]
+        ctx.packed, ctx.weights = packed, weights
+        ctx.param_versions = [(p.data_ptr(), p._version) for p in model._param_list()]
         return out_src, out_dst
 
     @staticmethod
@@ -88,19 +88,19 @@ class _TrainFunction(torch.autograd.Function):
         dev = ctx.ws.device
         g_src = (g_src if g_src is not None else torch.zeros((ctx.B, model.node_feat_dim), device=dev)).contiguous().float()
         g_dst = (g_dst if g_dst is not None else torch.zeros((ctx.B, model.node_feat_dim), device=dev)).contiguous().float()
-        params = list(model.parameters())
+        params = model._param_list()
         # the backward pass re-reads the CURRENT parameter values: they must be the ones the forward used (PyTorch raises the same
         # way when a tensor saved for backward was modified in place, e.g. by an optimizer step between forward and backward)
         if [(p.data_ptr(), p._version) for p in params] != ctx.param_versions:
             raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: "
                                "a DyGFormer parameter changed between this call's forward and its backward")
-        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)       # one fill for all gradient buffers
-        grads, o = [], 0
-        for p in params:
-            grads.append(flat[o:o + p.numel()].view_as(p))
-            o += p.numel()
-        gstruct = model._weights_struct(dict(zip((n for n, _ in model.named_parameters()), grads)))
-        weights = model._weights_struct()
+        sizes = model.__dict__.get("_psizes")
+        if sizes is None:
+            sizes = model.__dict__["_psizes"] = [p.numel() for p in params]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)       # one fill for all gradient buffers
+        grads = [g.view_as(p) for g, p in zip(flat.split(sizes), params)]
+        gstruct = model._weights_struct(grads)
+        weights = ctx.weights
         rc = model._lib.dygnn_dygformer_backward(C.byref(model._cfg), C.byref(weights), C.byref(gstruct), g_src.data_ptr(), g_dst.data_ptr(), ctx.B,
                                                  ctx.dropout_p, ctx.seed, C.cast(ctx.seq, C.c_void_p), ctx.ws.data_ptr(), ctx.ws.numel(),
                                                  ctx.packed.data_ptr(), _capi.current_stream_ptr())
@@ -176,7 +176,7 @@ class DyGFormer(nn.Module):
         B = src.numel()
         if not (dst.numel() == B and tms.numel() == B):
             raise AssertionError("src_node_ids, dst_node_ids and node_interact_times must have the same length")
-        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list())
         if (self.training or needs_grad) and B > 0 and _taps is None:
             if not self.training and not getattr(self, "_warned_eval_grad", False):
                 # eval mode with autograd recording is a legitimate call (gradients without dropout) but ~8x slower than inference:
@@ -187,7 +187,7 @@ class DyGFormer(nn.Module):
                 self._warned_eval_grad = True
             p_drop, seed = self._dropout_and_seed()
             seq_lens = self._seq_lens_side_stream(src_node_ids, dst_node_ids, node_interact_times, src, dst, tms, dev)
-            return _TrainFunction.apply(self, src, dst, tms, p_drop, seed, seq_lens, *self.parameters())
+            return _TrainFunction.apply(self, src, dst, tms, p_drop, seed, seq_lens, *self._param_list())
         out_src = torch.empty((B, self.node_feat_dim), dtype=torch.float32, device=dev)
         out_dst = torch.empty_like(out_src)
         if B == 0:
@@ -229,16 +229,16 @@ class DyGFormer(nn.Module):
         if src.dim() != 2 or src.shape != dst.shape or src.shape != tms.shape:
             raise AssertionError("expected three [N, B] arrays of equal shape")
         N, B = src.shape
-        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list())
         if (self.training or needs_grad) and N * B > 0:
             # training: the dense pass has ONE pair of padded lengths.  When every call of the set pads to the same lengths (the
             # usual case: some window of each call is full) the N calls are one pass over N*B pairs -- pairs never interact, so each
             # row equals the row of its own call and the parameter gradients are the sums of the per-call gradients, with half the
             # launches and no gradient-accumulation kernels; otherwise call by call.  Dropout masks are drawn per pass.
-            lens = self._seq_lens_groups(src, dst, tms, dev)
+            lens = self._seq_lens_groups(src_node_ids, dst_node_ids, node_interact_times, src, dst, tms, dev)
             if all(l == lens[0] for l in lens):
                 p_drop, seed = self._dropout_and_seed()
-                a, b = _TrainFunction.apply(self, src.reshape(-1), dst.reshape(-1), tms.reshape(-1), p_drop, seed, lens[0], *self.parameters())
+                a, b = _TrainFunction.apply(self, src.reshape(-1), dst.reshape(-1), tms.reshape(-1), p_drop, seed, lens[0], *self._param_list())
                 return a.reshape(N, B, -1), b.reshape(N, B, -1)
             outs = [self.compute_src_dst_node_temporal_embeddings(src[i], dst[i], tms[i]) for i in range(N)]
             return torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs])
@@ -249,7 +249,7 @@ class DyGFormer(nn.Module):
         return a.reshape(N, B, -1), b.reshape(N, B, -1)
 
     def _dropout_and_seed(self):
-        for p in self.parameters():
+        for p in self._param_list():
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise _capi.DygnnError("parameters must be contiguous float32")
         seed = getattr(self, "_fixed_dropout_seed", None)             # tests pin the masks; normally torch.manual_seed governs them
@@ -257,17 +257,27 @@ class DyGFormer(nn.Module):
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         return (float(self.dropout) if self.training else 0.0), seed
 
-    def _seq_lens_groups(self, src: torch.Tensor, dst: torch.Tensor, tms: torch.Tensor, dev):
-        """(S_src, S_dst) of each of the N calls in [N, B] device inputs, on the side stream (one synchronisation of it)."""
+    def _seq_lens_groups(self, src_in, dst_in, t_in, src: torch.Tensor, dst: torch.Tensor, tms: torch.Tensor, dev):
+        """(S_src, S_dst) of each of the N calls in [N, B] inputs, on the side stream (one synchronisation of IT, not of the main stream:
+        the host keeps queueing this step while the GPU still works on the previous one).  Host inputs are uploaded a second time on the
+        side stream; device inputs make the side stream wait for the main stream's copy of them."""
         side = getattr(self, "_side", None)
         if side is None or side.device != dev:
             side = self._side = torch.cuda.Stream(dev)
         L, P = self.max_input_sequence_length, self.patch_size
         N, B = src.shape
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
+        host = not any(isinstance(x, torch.Tensor) for x in (src_in, dst_in, t_in))
+        ev = None
+        if not host:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            side.wait_event(ev)
+            if host:
+                src = torch.from_numpy(np.ascontiguousarray(src_in, dtype=np.int64)).to(dev)
+                dst = torch.from_numpy(np.ascontiguousarray(dst_in, dtype=np.int64)).to(dev)
+                tms = torch.from_numpy(np.ascontiguousarray(t_in, dtype=np.float64)).to(dev)
+            else:
+                side.wait_event(ev)
             hist = torch.empty(B, dtype=torch.int32, device=dev)
             end = torch.empty(B, dtype=torch.int64, device=dev)
             maxw = torch.zeros(N, 2, dtype=torch.int32, device=dev)
@@ -277,7 +287,8 @@ class DyGFormer(nn.Module):
                     _capi.check(self._lib.dygnn_window_lengths(csr, nodes.data_ptr(), tms[i].data_ptr(), B, L, hist.data_ptr(), end.data_ptr(),
                                                                maxw[i, half:half + 1].data_ptr(), side.cuda_stream))
             m = maxw.cpu()                               # synchronises the side stream only
-        src.record_stream(side); dst.record_stream(side); tms.record_stream(side)
+        if not host:
+            src.record_stream(side); dst.record_stream(side); tms.record_stream(side)
         return [tuple((int(v) + 1) + (P - (int(v) + 1) % P) % P for v in row) for row in m.tolist()]
 
     def _seq_lens_side_stream(self, src_in, dst_in, t_in, src, dst, tms, dev):
@@ -364,9 +375,14 @@ class DyGFormer(nn.Module):
         w = _capi.DygformerWeights()
         if replace is None:
             p = lambda t: t.data_ptr()
-        else:
+        elif isinstance(replace, dict):
             by_id = {id(t): replace[n] for n, t in self.named_parameters()}
             p = lambda t: by_id[id(t)].data_ptr()
+        else:                           # a list aligned with self._param_list() (the backward pass: no module traversal per step)
+            index = self.__dict__.get("_pindex")
+            if index is None:
+                index = self.__dict__["_pindex"] = {id(t): i for i, t in enumerate(self._param_list())}
+            p = lambda t: replace[index[id(t)]].data_ptr()
         enc = self.neighbor_co_occurrence_encoder.neighbor_co_occurrence_encode_layer
         w.time_w, w.time_b = p(self.time_encoder.w.weight), p(self.time_encoder.w.bias)
         w.cooc_w0, w.cooc_b0, w.cooc_w1, w.cooc_b1 = p(enc[0].weight), p(enc[0].bias), p(enc[2].weight), p(enc[2].bias)
@@ -387,13 +403,22 @@ class DyGFormer(nn.Module):
         w.output_w, w.output_b = p(self.output_layer.weight), p(self.output_layer.bias)
         return w
 
-    def _packed_weights(self, dev):
-        """(ctypes view of the parameters, kernel-ready weight copy); both rebuilt whenever any parameter was written (optimizer
-        step, load_state_dict) — detected through the tensors' version counters and addresses."""
+    def _param_list(self):
         plist = self.__dict__.get("_plist")
         if plist is None:
             plist = self.__dict__["_plist"] = list(self.parameters())          # parameters are never added after construction
+        return plist
+
+    def _packed_weights(self, dev, training: bool = False):
+        """(ctypes view of the parameters, kernel-ready weight copy); both rebuilt whenever any parameter was written (optimizer
+        step, load_state_dict) — detected through the tensors' version counters and addresses."""
+        plist = self._param_list()
         key = tuple([(p.data_ptr(), p._version) for p in plist]) + (str(dev),)
+        if self._packed is not None and self._packed_key == key and not training and not self.__dict__.get("_packed_complete", True):
+            # the training path refreshed the fragment streams only: bring the inference sections up to date too
+            _capi.check(self._lib.dygnn_dygformer_repack(C.byref(self._cfg), C.byref(self._weights_cached), self._packed.data_ptr(), self._packed.numel(), 0,
+                                                         _capi.current_stream_ptr()))
+            self.__dict__["_packed_complete"] = True
         if self._packed is None or self._packed_key != key:
             for p in plist:
                 if p.dtype != torch.float32 or not p.is_contiguous():
@@ -408,12 +433,15 @@ class DyGFormer(nn.Module):
             ptrs = tuple(k[0] for k in key[:-1]) + (self._packed.data_ptr(),)
             # an optimizer step changes the values, not the addresses: the fragment descriptors already in the buffer stay valid and the
             # refresh is kernel launches only (no host synchronisation inside the training loop)
-            if not fresh and self.__dict__.get("_packed_ptrs") == ptrs:
-                fn = self._lib.dygnn_dygformer_repack
-            else:
-                fn = self._lib.dygnn_dygformer_pack
+            repack = not fresh and self.__dict__.get("_packed_ptrs") == ptrs
             self.__dict__["_packed_ptrs"] = None
-            _capi.check(fn(C.byref(self._cfg), C.byref(weights), self._packed.data_ptr(), nbytes, _capi.current_stream_ptr()))
+            if repack:
+                _capi.check(self._lib.dygnn_dygformer_repack(C.byref(self._cfg), C.byref(weights), self._packed.data_ptr(), nbytes, 1 if training else 0,
+                                                             _capi.current_stream_ptr()))
+                self.__dict__["_packed_complete"] = not training
+            else:
+                _capi.check(self._lib.dygnn_dygformer_pack(C.byref(self._cfg), C.byref(weights), self._packed.data_ptr(), nbytes, _capi.current_stream_ptr()))
+                self.__dict__["_packed_complete"] = True
             self.__dict__["_packed_ptrs"] = ptrs
             self._packed_key = key
         return self._weights_cached, self._packed

@@ -162,9 +162,11 @@ size_t dygnn_dygformer_packed_bytes(const dygnn_dygformer_config* cfg_host);
 int dygnn_dygformer_pack(const dygnn_dygformer_config* cfg_host, const dygnn_dygformer_weights* w_host,
                          void* packed, size_t packed_bytes, dygnn_stream_t stream);
 /* The weights changed IN PLACE (an optimizer step: same device addresses as at the last dygnn_dygformer_pack into `packed`):
- * refresh the copy with kernel launches only — no host work, no synchronisation (train_link_prediction.py:257 runs once per step). */
+ * refresh the copy with kernel launches only — no host work, no synchronisation (train_link_prediction.py:257 runs once per step).
+ * fused_only != 0 refreshes just what the training entry points read (the fragment streams: two launches); the co-occurrence table and
+ * the transposed copies of the inference paths are then stale until a call with fused_only = 0. */
 int dygnn_dygformer_repack(const dygnn_dygformer_config* cfg_host, const dygnn_dygformer_weights* w_host,
-                           void* packed, size_t packed_bytes, dygnn_stream_t stream);
+                           void* packed, size_t packed_bytes, int32_t fused_only, dygnn_stream_t stream);
 
 size_t dygnn_dygformer_workspace_bytes(const dygnn_dygformer_config* cfg_host, int64_t batch);
 /* the same for one implementation choice (`impl` of dygnn_dygformer_forward): the fused kernels need only the per-query search

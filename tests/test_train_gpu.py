@@ -154,8 +154,10 @@ def test_many_in_training_equals_separate_calls(name, equal_lengths):
     B = len(c["src"])
     G = [torch.from_numpy(g).cuda() for g in (_loss_weights(c, 5) + _loss_weights(c, 6))]
     src2, dst2 = (c["src"], c["neg_dst"]) if equal_lengths else (c["dst"], c["src"])
-    lens = model._seq_lens_groups(*(torch.from_numpy(np.stack(x)).cuda() for x in ([c["src"], src2], [c["dst"], dst2], [c["times"], c["times"]])),
-                                  torch.device("cuda:0"))
+    host = [np.stack(x) for x in ([c["src"], src2], [c["dst"], dst2], [c["times"], c["times"]])]
+    devt = [torch.from_numpy(x).cuda() for x in host]
+    lens = model._seq_lens_groups(*host, *devt, torch.device("cuda:0"))                  # host inputs: uploaded on the side stream
+    assert lens == model._seq_lens_groups(*devt, *devt, torch.device("cuda:0"))          # device inputs: the side stream waits for them
     assert (lens[0] == lens[1]) == equal_lengths, lens
 
     def loss_of(ps, pd, ns, nd):
