@@ -893,7 +893,31 @@ __global__ void k_lut_fwd(const float* __restrict__ w0, const float* __restrict_
         lut[c * C + j] = acc;
     }
 }
-// time-encoder gradients from dPt [M][P*Ft]: pre = w dt + b, d cos = -sin(pre)
+// sin of the time encoder's argument (up to ~3e6 rad): the range reduction of the forward's cosine (dygformer_fused3.hip cos_time) a quarter
+// turn on: x / (2 pi) as a two-float product, the fraction folded to [0, 0.25], cos(2 pi u) by an even polynomial; libm's sinf takes its slow
+// Payne-Hanek path for such arguments and is kept only beyond the product's accuracy
+__device__ __forceinline__ float sin_time(float x) {
+    if (!(fabsf(x) <= 3.0e7f)) return sinf(x);
+    const float INV_HI = 0.15915493667125702f, INV_LO = 6.4206382432985265e-09f;
+    const float p = x * INV_HI;
+    const float e = fmaf(x, INV_HI, -p);
+    const float q = fmaf(x, INV_LO, e);
+    float t = ((p - rintf(p)) + q) - 0.25f;               // sin(2 pi t') = cos(2 pi (t' - 1/4))
+    t -= rintf(t);
+    float u = fabsf(t);
+    const bool flip = u > 0.25f;
+    const float v = flip ? 0.5f - u : u;
+    const float z = v * v;
+    float r = fmaf(7.903536371318467f, z, -26.42625678337438f);
+    r = fmaf(r, z, 60.24464137187666f);
+    r = fmaf(r, z, -85.45681720669373f);
+    r = fmaf(r, z, 64.93939402266829f);
+    r = fmaf(r, z, -19.739208802178716f);
+    r = fmaf(r, z, 1.0f);
+    return flip ? -r : r;
+}
+// time-encoder gradients from dPt [M][P*Ft]: pre = w dt + b, d cos = -sin(pre).  One workgroup per pair, thread = column k = pp * Ft + f of
+// the pair's rows (coalesced), its sums over the T tokens in registers; the P columns of a feature meet in LDS, one atomic per feature.
 __global__ __launch_bounds__(256) void k_time_bwd(const float* __restrict__ dPt, const int32_t* __restrict__ ids, const float* __restrict__ dts,
                                                     const float* __restrict__ tw, const float* __restrict__ tb, int64_t B, int Ss, int Sd, int Ts, int T,
                                                     int P, int Ft, float* __restrict__ dw, float* __restrict__ db) {
@@ -902,14 +926,19 @@ __global__ __launch_bounds__(256) void k_time_bwd(const float* __restrict__ dPt,
     __syncthreads();
     const int S = Ss + Sd, Kt = P * Ft;
     const int64_t b = blockIdx.x;
-    for (int idx = threadIdx.x; idx < T * Kt; idx += 256) {
-        const int tok = idx / Kt, k = idx - tok * Kt, f = k % Ft;
-        const int pp = (tok < Ts ? tok * P : Ss + (tok - Ts) * P) + k / Ft;
-        if (ids[b * S + pp] == 0) continue;
-        const float dt = dts[b * S + pp];
-        const float gsin = -sinf(fmaf(dt, tw[f], tb[f])) * dPt[(b * T + tok) * Kt + k];
-        atomicAdd(&part[f], gsin * dt);
-        atomicAdd(&part[Ft + f], gsin);
+    for (int k = threadIdx.x; k < Kt; k += 256) {
+        const int pp = k / Ft, f = k - pp * Ft;
+        const float w = tw[f], bb = tb[f];
+        float gw = 0.f, gb = 0.f;
+        for (int tok = 0; tok < T; ++tok) {
+            const int pos = (tok < Ts ? tok * P : Ss + (tok - Ts) * P) + pp;
+            if (ids[b * S + pos] == 0) continue;
+            const float dt = dts[b * S + pos];
+            const float gsin = -sin_time(fmaf(dt, w, bb)) * dPt[(b * T + tok) * Kt + k];
+            gw = fmaf(gsin, dt, gw); gb += gsin;
+        }
+        atomicAdd(&part[f], gw);
+        atomicAdd(&part[Ft + f], gb);
     }
     __syncthreads();
     for (int k = threadIdx.x; k < Ft; k += 256) { atomicAdd(&dw[k], part[k]); atomicAdd(&db[k], part[Ft + k]); }
@@ -918,7 +947,7 @@ __global__ __launch_bounds__(256) void k_time_bwd(const float* __restrict__ dPt,
 // One workgroup handles kPairsPerWg pairs.  Thread (grp, j) owns column j of its own LDS copy [grp][count < 16][C] and walks
 // every 5th (token, position) of the pair, so the hot counts (0, 1, 2, ...) are summed without atomics; the five copies are
 // then folded into the global table with one atomic per (count, column) and workgroup.  Counts >= 16 go straight to global.
-constexpr int kCoocRows = 16, kCoocGroups = 5, kPairsPerWg = 8;
+constexpr int kCoocRows = 16, kCoocGroups = 5, kPairsPerWg = 1;      // one pair per workgroup: the walk is a chain of load latencies, so what pays is more workgroups
 __global__ __launch_bounds__(256) void k_cooc_bwd(const float* __restrict__ dPc, const int32_t* __restrict__ c0, const int32_t* __restrict__ c1, int64_t B,
                                                     int Ss, int Sd, int Ts, int T, int P, int C, float* __restrict__ dlut) {
     extern __shared__ float acc[];             // [5][16][C]
@@ -958,25 +987,34 @@ __global__ void k_lut_bwd_hidden(const float* __restrict__ dlut, const float* __
     }
 }
 // dw1[j][k] = sum_c dlut[c][j] hid[c][k] ; db1[j] = sum_c dlut[c][j] ; dw0[k] = sum_c dh[c][k] * c ; db0[k] = sum_c dh[c][k]
+// (three [rows][C] tables, rows <= 2 Smax + 1: staged in LDS once per workgroup, the sums then run from LDS instead of as chains of global loads)
+constexpr int kLutChunk = 128;                 // table rows staged per pass
 __global__ __launch_bounds__(256) void k_lut_bwd(const float* __restrict__ dlut, const float* __restrict__ hid, const float* __restrict__ dh, int rows, int C,
                                                    float* __restrict__ dw0, float* __restrict__ db0, float* __restrict__ dw1, float* __restrict__ db1) {
+    extern __shared__ float lsm[];             // dlut | hid | dh, each [kLutChunk][C]
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx < C * C) {
-        const int j = idx / C, k = idx % C;
-        float acc = 0.f;
-        for (int c = 0; c < rows; ++c) acc = fmaf(dlut[c * C + j], hid[c * C + k], acc);
-        dw1[idx] = acc;
-    } else if (idx < C * C + C) {
-        const int j = idx - C * C;
-        float acc = 0.f;
-        for (int c = 0; c < rows; ++c) acc += dlut[c * C + j];
-        db1[j] = acc;
-    } else if (idx < C * C + 2 * C) {
-        const int k = idx - C * C - C;
-        float aw = 0.f, ab = 0.f;
-        for (int c = 0; c < rows; ++c) { const float v = dh[c * C + k]; aw = fmaf(v, (float)c, aw); ab += v; }
-        dw0[k] = aw; db0[k] = ab;
+    const int nmax = kLutChunk * C;
+    const float *sl = lsm, *sh = lsm + nmax, *sd = lsm + 2 * nmax;
+    float acc = 0.f, acc2 = 0.f;
+    for (int r0 = 0; r0 < rows; r0 += kLutChunk) {
+        const int nr = rows - r0 < kLutChunk ? rows - r0 : kLutChunk, n = nr * C;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) { lsm[i] = dlut[r0 * C + i]; lsm[nmax + i] = hid[r0 * C + i]; lsm[2 * nmax + i] = dh[r0 * C + i]; }
+        __syncthreads();
+        if (idx < C * C) {
+            const int j = idx / C, k = idx % C;
+            for (int c = 0; c < nr; ++c) acc = fmaf(sl[c * C + j], sh[c * C + k], acc);
+        } else if (idx < C * C + C) {
+            const int j = idx - C * C;
+            for (int c = 0; c < nr; ++c) acc += sl[c * C + j];
+        } else if (idx < C * C + 2 * C) {
+            const int k = idx - C * C - C;
+            for (int c = 0; c < nr; ++c) { const float v = sd[c * C + k]; acc = fmaf(v, (float)(r0 + c), acc); acc2 += v; }
+        }
     }
+    if (idx < C * C) dw1[idx] = acc;
+    else if (idx < C * C + C) db1[idx - C * C] = acc;
+    else if (idx < C * C + 2 * C) { dw0[idx - C * C - C] = acc; db0[idx - C * C - C] = acc2; }
 }
 
 // pooled[side][b][:] = mean over the side's tokens (DyGFormer.py:181-187)
@@ -1273,7 +1311,8 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
     float* dh = F32(p.dPc);        // dPc is dead now: reuse its head for dh [S+1][C]
     hipLaunchKernelGGL(k_lut_bwd_hidden, dim3((unsigned)(S + 1)), dim3(64), 0, s, F32(p.dlut), F32(p.hid), w->cooc_w1, C, dh);
     DYGNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_lut_bwd, dim3((unsigned)ceil_div(C * C + 2 * C, 256)), dim3(256), 0, s, F32(p.dlut), F32(p.hid), dh, S + 1, C, G(grads->cooc_w0),
+    DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lut_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_lut_bwd, dim3((unsigned)ceil_div(C * C + 2 * C, 256)), dim3(256), (size_t)3 * kLutChunk * C * sizeof(float), s, F32(p.dlut), F32(p.hid), dh, S + 1, C, G(grads->cooc_w0),
                        G(grads->cooc_b0), G(grads->cooc_w1), G(grads->cooc_b1));
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
