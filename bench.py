@@ -498,6 +498,9 @@ def bench_tgn(dev, steps: int = 100, warmup: int = 60, cpu_budget_s: float = 10.
     host = [(data.src_node_ids[i * B:(i + 1) * B], data.dst_node_ids[i * B:(i + 1) * B], syn.random_negative_dst(rs, ud, B),
              data.node_interact_times[i * B:(i + 1) * B], data.edge_ids[i * B:(i + 1) * B]) for i in range(n)]
     batches = [tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in b) for b in host]
+    # the step as ONE resident batch [positives ; negatives] (what compute_step_embeddings builds from its four id arrays)
+    joint = [tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (np.concatenate([s_, s_]), np.concatenate([d_, n_]), np.concatenate([t_, t_]), e_))
+             for s_, d_, n_, t_, e_ in host]
 
     def step(i):
         s, d, ng, t, e = batches[i]
@@ -506,8 +509,9 @@ def bench_tgn(dev, steps: int = 100, warmup: int = 60, cpu_budget_s: float = 10.
                 a, b_ = model.compute_src_dst_node_temporal_embeddings(s, ng, t, edge_ids=None, edges_are_positive=False, num_neighbors=K)
                 c, f = model.compute_src_dst_node_temporal_embeddings(s, d, t, edge_ids=e, edges_are_positive=True, num_neighbors=K)
                 return merge.link_probabilities(c, f), merge.link_probabilities(a, b_)
-            c, f, a, b_ = model.compute_step_embeddings(s, d, s, ng, t, e, num_neighbors=K)      # both calls as one (same state, written once at the end)
-            p = merge.link_probabilities(torch.cat([c, a]), torch.cat([f, b_]))
+            s2, d2, t2, e2 = joint[i]         # both calls as one (same state, written once at the end); no per-step concatenation kernels
+            se, de = model.compute_step_embeddings_joint(s2, d2, t2, e2, B, num_neighbors=K)
+            p = merge.link_probabilities(se, de)
             return p[:B], p[B:]
     model.memory_bank.__init_memory_bank__()
     for i in range(warmup):

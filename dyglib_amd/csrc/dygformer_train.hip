@@ -449,6 +449,10 @@ int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb,
         //  * 64-column tiles unless 128-column tiles pad clearly less (N = 272 pads to 320 instead of 384): TGN +38 %, TGAT +14 %.
         // both operands by LDS-DMA when no float4 can straddle a bound (see k_mm_dma)
         const char* dma_env = getenv("DYGNN_MM_DMA");
+        // (Measured and not kept, round 2: the 32 x 208-per-wave register tile of k_dw_grouped applied to the tall activation x weight products
+        //  of TGAT — M ~ 10^5, N and K of 136 .. 444: 26 MFMAs per 15 LDS operand reads — ran them in the SAME time as these 64 x 64 tiles
+        //  (16.5 vs 16.1 ms over a profile): with K this short a workgroup lives for 9 .. 28 k-steps and its ring fill and tile write-out,
+        //  not the k-loop's MFMA density, set the pace.)
         if (vecA && vecB && K % 4 == 0 && (!tA || M % 4 == 0) && (tB || N % 4 == 0) && !(dma_env && dma_env[0] == '0')) {
             // measured: 64 x 64 tiles with a 4-stage ring; 3 stages tie, 6 / 8 stages and 128 x 128 tiles (3 stages) lose occupancy and are slower
             launch_mm_dma<2, 2, 4>(s, p, tA, tB, batch);

@@ -103,6 +103,13 @@ def evaluate_model_link_prediction(model_name: str, model: nn.Module, neighbor_s
         else:       # TGN: batches strictly in sequence; the negative and the positive call of a batch (:85-107) are one library call
             probs = []
             for gp, gn in zip(groups_pos, groups_neg):
+                if all(isinstance(x, np.ndarray) for x in (gp[0], gp[1], gn[0], gn[1], gp[2])) and len(gp[0]) == len(gn[0]):
+                    # host batches: [positives ; negatives] joined on the host, one library call, one link-predictor launch over its output
+                    n = len(gp[0])
+                    se, de = backbone.compute_step_embeddings_joint(np.concatenate([gp[0], gn[0]]), np.concatenate([gp[1], gn[1]]), np.concatenate([gp[2], gp[2]]),
+                                                                    gp[3], n, num_neighbors=num_neighbors)
+                    probs.append(merge.link_probabilities(se, de).view(2, n))
+                    continue
                 ps, pd, ns, nd = backbone.compute_step_embeddings(gp[0], gp[1], gn[0], gn[1], gp[2], gp[3], num_neighbors=num_neighbors)
                 probs.append(torch.stack([merge.link_probabilities(ps, pd), merge.link_probabilities(ns, nd)]))
             prob = torch.stack(probs, dim=1)

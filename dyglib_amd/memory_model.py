@@ -133,6 +133,13 @@ class MemoryModel(nn.Module):
                                                              num_neighbors=num_neighbors, _n_positive=n_pos)
         return s[:n_pos], d[:n_pos], s[n_pos:], d[n_pos:]
 
+    def compute_step_embeddings_joint(self, src_pos_neg, dst_pos_neg, times_pos_neg, edge_ids, n_positive: int, num_neighbors: int = 20):
+        """compute_step_embeddings for a caller that already holds the step as ONE batch [positives ; negatives] (ids and times [2B], edge
+        ids [B]): returns (src_emb, dst_emb) [2B, dim] as the library wrote them — rows 0 .. n_positive-1 are the positive call's, the rest the
+        negative call's — so neither the inputs nor the link predictor's operands are concatenated on the device per step."""
+        return self.compute_src_dst_node_temporal_embeddings(src_pos_neg, dst_pos_neg, times_pos_neg, edge_ids, edges_are_positive=True,
+                                                             num_neighbors=num_neighbors, _n_positive=int(n_positive))
+
     def compute_src_dst_node_temporal_embeddings(self, src_node_ids, dst_node_ids, node_interact_times, edge_ids,
                                                  edges_are_positive: bool = True, num_neighbors: int = 20, _n_positive: int = None
                                                  ) -> Tuple[torch.Tensor, torch.Tensor]:
