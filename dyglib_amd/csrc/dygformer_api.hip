@@ -1,5 +1,6 @@
 // C-ABI entry points for the DyGFormer forward path + the fused link-predictor head.
 #include "dygformer_layout.h"
+#include "gemm.h"
 
 namespace dygnn {
 // dygformer_generic.hip
@@ -180,158 +181,129 @@ __global__ __launch_bounds__(256) void k_merge_sigmoid_mid(const float* __restri
 }
 
 // Backward of the link predictor z = fc2(relu(fc1(cat(a, b)))) for the training step (train_link_prediction.py:241-257; models/modules.py:57-68):
-// given g = dL/dz [n] it produces da, db [n][dim] and the four parameter gradients.  The whole head is 0.1 GFLOP per step, so this is plain
-// FMA code organised around its memory shapes, in two launches and without atomics (float atomics take ~3,000 cycles to retire under load and
-// every later load of the wave waits behind them: a first single-kernel version with one atomic per dfc1 element spent 80 us on that):
-//   k_merge_bwd_w : one workgroup = 8 hidden units j, ALL rows.  Per block of 256 rows: thread = row recomputes the 8 pre-activations
-//                   (fc1 rows from LDS) and leaves dh = g w2 [pre > 0] in LDS and in `dh` [n][hidden]; thread = input feature k then
-//                   accumulates dfc1[j][k] += dh[row][j] cat[row][k] over the block (coalesced feature reads).  Plain stores at the end;
-//                   dfc1_b, dfc2_w by wave reductions, dfc2_b by workgroup 0.
-//   k_merge_bwd_x : one workgroup = 8 rows: dcat[row][k] = sum_j dh[row][j] fc1[j][k], thread = k, coalesced fc1 reads.
-constexpr int kMergeJ = 8, kMergeRows = 8;
-__global__ __launch_bounds__(256) void k_merge_bwd_w(const float* __restrict__ a, const float* __restrict__ b, int64_t n, int dim, int hidden,
-                                                      const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
-                                                      const float* __restrict__ gz, float* __restrict__ dh, float* __restrict__ dw1,
-                                                      float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2) {
-    extern __shared__ __attribute__((aligned(16))) float msm[];
-    const int K = 2 * dim, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j0 = blockIdx.x * kMergeJ;
-    float* wj = msm;                          // [8][K] fc1 rows of this workgroup's hidden units
-    float* dhs = wj + kMergeJ * K;            // [256][8]
-    float* red = dhs + 256 * kMergeJ;         // [4 waves][2][8] (+ 4 for dfc2_b)
-    for (int idx = tid; idx < kMergeJ * K; idx += 256) {
-        const int j = idx / K;
-        wj[idx] = j0 + j < hidden ? w1[(size_t)(j0 + j) * K + (idx - j * K)] : 0.f;
-    }
-    float bj[kMergeJ], vj[kMergeJ];
+// given g = dL/dz [n] it produces da, db [n][dim] and ACCUMULATES the four parameter gradients (buffers zeroed by the caller).
+// k_merge_bwd_rows, one workgroup = 16 rows (the forward kernel above with a different ending):
+//   * hidden pre-activations on the matrix cores exactly as k_merge_sigmoid_mid (wave w: three 16-wide hidden tiles from 48 w);
+//   * dh = g w2 [pre > 0] leaves as rows [n][hidden] (the operand of the weight-gradient product below) and, transposed, into LDS; dfc2_w from the
+//     accumulators (DPP row sums, one atomic per hidden unit and workgroup), dfc2_b likewise;
+//   * dcat = dh fc1 on the matrix cores: out^T[k][row] = sum_j fc1[j][k] dh^T[j][row].  One float4 of an fc1 row (4 consecutive k) per lane feeds FOUR
+//     MFMAs whose output rows are k = 4 c + t: the 16 lanes of a group cover 64 consecutive k, each lane ends up with 16 consecutive k per lane group;
+// dfc1 = dh^T [a | b] (+ dfc1_b = column sums of dh) is a weight-gradient-shaped product: train::dw_grouped (k_dw_grouped), two problems.
+// (Two earlier FMA-only versions — one atomic per dfc1 element, then two atomics-free kernels — took 80-90 us per call: chains of load and atomic
+// latencies on 25 workgroups.)
+__global__ __launch_bounds__(256) void k_merge_bwd_rows(const float* __restrict__ a, const float* __restrict__ b, int64_t n_rows, int dim, int hidden,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                         const float* __restrict__ gz, float* __restrict__ dh, int ldh, float* __restrict__ da,
+                                                         float* __restrict__ db, float* __restrict__ dw2, float* __restrict__ db2) {
+    __shared__ float dhs[192][17];             // dh^T [hidden][row] (+1: the transposed reads below hit 16 different banks)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t m = (int64_t)blockIdx.x * 16 + c;
+    const bool mv = m < n_rows;
+    const int K = 2 * dim, nsteps = (K + 15) >> 4;
+    constexpr int PF = 4;
+    const int n0 = 48 * wave;
+    auto load_b = [&](int st) -> mf4 {
+        const int kk = 16 * st + 4 * g;
+        if (!(mv && kk < K)) return mf4{0.f, 0.f, 0.f, 0.f};
+        return kk < dim ? *reinterpret_cast<const mf4*>(a + m * dim + kk) : *reinterpret_cast<const mf4*>(b + m * dim + (kk - dim));
+    };
+    auto load_a = [&](int st, int i) -> mf4 {
+        const int kk = 16 * st + 4 * g, n = n0 + 16 * i + c;
+        return (n < hidden && kk < K) ? *reinterpret_cast<const mf4*>(w1 + (size_t)n * K + kk) : mf4{0.f, 0.f, 0.f, 0.f};
+    };
+    mf4 acc[3] = {mf4{0.f, 0.f, 0.f, 0.f}, mf4{0.f, 0.f, 0.f, 0.f}, mf4{0.f, 0.f, 0.f, 0.f}};
+    {
+        mf4 bq[PF], aq[PF][3];
 #pragma unroll
-    for (int j = 0; j < kMergeJ; ++j) { bj[j] = j0 + j < hidden ? b1[j0 + j] : 0.f; vj[j] = j0 + j < hidden ? w2[j0 + j] : 0.f; }
-    float accw[2][kMergeJ];                   // dfc1[j0 + j][k], k = tid and tid + 256
+        for (int u = 0; u < PF; ++u) {
+            bq[u] = load_b(u);
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+            for (int i = 0; i < 3; ++i) aq[u][i] = load_a(u, i);
+        }
+        for (int st0 = 0; st0 < nsteps; st0 += PF) {
 #pragma unroll
-        for (int j = 0; j < kMergeJ; ++j) accw[q][j] = 0.f;
-    float sb[kMergeJ], sw[kMergeJ], sg = 0.f;  // this thread's share of dfc1_b, dfc2_w, dfc2_b
+            for (int u = 0; u < PF; ++u) {
+                if (st0 + u < nsteps) {
+                    const mf4 bf = bq[u];
+                    mf4 af[3];
 #pragma unroll
-    for (int j = 0; j < kMergeJ; ++j) { sb[j] = 0.f; sw[j] = 0.f; }
-    __syncthreads();
-    for (int64_t r0 = 0; r0 < n; r0 += 256) {
-        const int64_t row = r0 + tid;
-        float pre[kMergeJ];
+                    for (int i = 0; i < 3; ++i) af[i] = aq[u][i];
+                    bq[u] = load_b(st0 + u + PF);
 #pragma unroll
-        for (int j = 0; j < kMergeJ; ++j) pre[j] = bj[j];
-        if (row < n) {
-            // these loops are chains of global-load latencies unless the loads are batched: eight float4 of the row in flight at a time
-            constexpr int LB = 8;
-            for (int k0 = 0; k0 < K; k0 += 4 * LB) {
-                mf4 cq[LB];
+                    for (int i = 0; i < 3; ++i) aq[u][i] = load_a(st0 + u + PF, i);
 #pragma unroll
-                for (int u = 0; u < LB; ++u) {
-                    const int k = k0 + 4 * u;
-                    cq[u] = k >= K ? mf4{0.f, 0.f, 0.f, 0.f} : (k < dim ? *reinterpret_cast<const mf4*>(a + row * dim + k) : *reinterpret_cast<const mf4*>(b + row * dim + (k - dim)));
-                }
+                    for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int u = 0; u < LB; ++u) {
-                    const int k = k0 + 4 * u;
-                    if (k < K) {
-#pragma unroll
-                        for (int j = 0; j < kMergeJ; ++j) {
-                            const mf4 wv = *reinterpret_cast<const mf4*>(wj + j * K + k);
-                            pre[j] = fmaf(wv.x, cq[u].x, fmaf(wv.y, cq[u].y, fmaf(wv.z, cq[u].z, fmaf(wv.w, cq[u].w, pre[j]))));
-                        }
-                    }
+                        for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[t], acc[i], 0, 0, 0);
                 }
             }
         }
-        const float g = row < n ? gz[row] : 0.f;
-        sg += g;
+    }
+    // dh, dfc2_w, dfc2_b from the accumulators (rows = hidden units n0 + 16 i + 4 g + r, columns = the 16 rows of the workgroup)
+    const float gm = mv ? gz[m] : 0.f;
 #pragma unroll
-        for (int j = 0; j < kMergeJ; ++j) {
-            const float d = pre[j] > 0.f ? g * vj[j] : 0.f;
-            dhs[tid * kMergeJ + j] = d;
-            if (row < n && j0 + j < hidden) dh[row * hidden + j0 + j] = d;
-            sb[j] += d; sw[j] = fmaf(fmaxf(pre[j], 0.f), g, sw[j]);
+    for (int i = 0; i < 3; ++i) {
+        mf4 d, hr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + 16 * i + 4 * g + r;
+            const float pre = n < hidden ? acc[i][r] + b1[n] : 0.f;
+            d[r] = (n < hidden && pre > 0.f) ? gm * w2[n] : 0.f;
+            hr[r] = fmaxf(pre, 0.f) * gm;
+            dhs[n][c] = d[r];
         }
-        __syncthreads();
-        const int nr = n - r0 < 256 ? (int)(n - r0) : 256;
+        const int nb = n0 + 16 * i + 4 * g;
+        if (mv && nb < hidden) *reinterpret_cast<mf4*>(dh + m * ldh + nb) = d;          // hidden % 4 == 0: a float4 never straddles the end
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int k = tid + 256 * q;
-            if (k < K) {
-                const float* src = k < dim ? a + r0 * dim + k : b + r0 * dim + (k - dim);
-                constexpr int RB = 16;
-                for (int rb = 0; rb < nr; rb += RB) {
-                    float cq[RB];
+        for (int r = 0; r < 4; ++r) {
+            float v = hr[r];                    // sum over the 16 rows (lanes of one group)
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if (c == 0 && nb + r < hidden) atomicAdd(dw2 + nb + r, v);
+        }
+    }
+    if (wave == 0) {
+        float v = g == 0 ? gm : 0.f;
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        if (lane == 0) atomicAdd(db2, v);
+    }
+    __syncthreads();
+    // dcat: sets of 64 consecutive input features k, dealt to the waves; per k-step of 4 hidden units one float4 of fc1 per lane and four MFMAs
+    const int nset = (K + 63) >> 6, hsteps = (hidden + 3) >> 2;
+    for (int set = wave; set < nset; set += 4) {
+        const int kbase = 64 * set, kl = kbase + 4 * c;            // this lane's four features
+        mf4 o[4] = {mf4{0.f, 0.f, 0.f, 0.f}, mf4{0.f, 0.f, 0.f, 0.f}, mf4{0.f, 0.f, 0.f, 0.f}, mf4{0.f, 0.f, 0.f, 0.f}};
+        auto load_w = [&](int hs) -> mf4 {
+            const int j = 4 * hs + g;
+            return (j < hidden && kl < K) ? *reinterpret_cast<const mf4*>(w1 + (size_t)j * K + kl) : mf4{0.f, 0.f, 0.f, 0.f};
+        };
+        constexpr int WQ = 8;
+        mf4 wq[WQ];
 #pragma unroll
-                    for (int u = 0; u < RB; ++u) cq[u] = rb + u < nr ? src[(size_t)(rb + u) * dim] : 0.f;
+        for (int u = 0; u < WQ; ++u) wq[u] = load_w(u);
+        for (int hs0 = 0; hs0 < hsteps; hs0 += WQ) {
 #pragma unroll
-                    for (int u = 0; u < RB; ++u) {
-                        const int r = rb + u < nr ? rb + u : 0;          // beyond the block: cq = 0
-                        const float cv = cq[u];
-                        const mf4 d0 = *reinterpret_cast<const mf4*>(dhs + r * kMergeJ), d1 = *reinterpret_cast<const mf4*>(dhs + r * kMergeJ + 4);
-                        accw[q][0] = fmaf(d0.x, cv, accw[q][0]); accw[q][1] = fmaf(d0.y, cv, accw[q][1]); accw[q][2] = fmaf(d0.z, cv, accw[q][2]); accw[q][3] = fmaf(d0.w, cv, accw[q][3]);
-                        accw[q][4] = fmaf(d1.x, cv, accw[q][4]); accw[q][5] = fmaf(d1.y, cv, accw[q][5]); accw[q][6] = fmaf(d1.z, cv, accw[q][6]); accw[q][7] = fmaf(d1.w, cv, accw[q][7]);
-                    }
+            for (int u = 0; u < WQ; ++u) {
+                if (hs0 + u < hsteps) {
+                    const mf4 wv = wq[u];
+                    wq[u] = load_w(hs0 + u + WQ);
+                    const int j = 4 * (hs0 + u) + g;
+                    const float bv = j < hidden ? dhs[j][c] : 0.f;      // B[k = hidden unit j][n = row c]
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], bv, o[t], 0, 0, 0);
                 }
             }
         }
-        __syncthreads();
-    }
+        // o[t][r] = dcat[row c][k = kbase + 4 (4 g + r) + t]: 16 consecutive features per lane
+        if (mv) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int k = tid + 256 * q;
-        if (k < K)
-#pragma unroll
-            for (int j = 0; j < kMergeJ; ++j)
-                if (j0 + j < hidden) dw1[(size_t)(j0 + j) * K + k] = accw[q][j];
-    }
-#pragma unroll
-    for (int j = 0; j < kMergeJ; ++j) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { sb[j] += __shfl_xor(sb[j], o, 64); sw[j] += __shfl_xor(sw[j], o, 64); }
-        if (lane == 0) { red[(wave * 2 + 0) * kMergeJ + j] = sb[j]; red[(wave * 2 + 1) * kMergeJ + j] = sw[j]; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sg += __shfl_xor(sg, o, 64);
-    if (lane == 0) red[8 * kMergeJ + wave] = sg;
-    __syncthreads();
-    if (tid < 2 * kMergeJ) {
-        const int which = tid / kMergeJ, j = tid % kMergeJ;
-        const float t = (red[(0 * 2 + which) * kMergeJ + j] + red[(1 * 2 + which) * kMergeJ + j]) + (red[(2 * 2 + which) * kMergeJ + j] + red[(3 * 2 + which) * kMergeJ + j]);
-        if (j0 + j < hidden) (which ? dw2 : db1)[j0 + j] = t;
-    }
-    if (blockIdx.x == 0 && tid == 0) db2[0] = (red[8 * kMergeJ] + red[8 * kMergeJ + 1]) + (red[8 * kMergeJ + 2] + red[8 * kMergeJ + 3]);
-}
-__global__ __launch_bounds__(256) void k_merge_bwd_x(int64_t n, int dim, int hidden, const float* __restrict__ w1, const float* __restrict__ dh,
-                                                      float* __restrict__ da, float* __restrict__ db) {
-    extern __shared__ __attribute__((aligned(16))) float msm[];      // dh rows [8][hidden]
-    const int K = 2 * dim, tid = threadIdx.x;
-    const int64_t row0 = (int64_t)blockIdx.x * kMergeRows;
-    for (int idx = tid; idx < kMergeRows * hidden; idx += 256) {
-        const int r = idx / hidden;
-        msm[idx] = row0 + r < n ? dh[(row0 + r) * hidden + (idx - r * hidden)] : 0.f;
-    }
-    __syncthreads();
-    for (int k = tid; k < K; k += 256) {
-        float acc[kMergeRows];
-#pragma unroll
-        for (int r = 0; r < kMergeRows; ++r) acc[r] = 0.f;
-        constexpr int JB = 16;               // fc1 values in flight per thread
-        for (int j0 = 0; j0 < hidden; j0 += JB) {
-            float wq[JB];
-#pragma unroll
-            for (int u = 0; u < JB; ++u) wq[u] = j0 + u < hidden ? w1[(size_t)(j0 + u) * K + k] : 0.f;
-#pragma unroll
-            for (int u = 0; u < JB; ++u) {
-                const int j = j0 + u < hidden ? j0 + u : 0;
-#pragma unroll
-                for (int r = 0; r < kMergeRows; ++r) acc[r] = fmaf(msm[r * hidden + j], wq[u], acc[r]);
+            for (int r = 0; r < 4; ++r) {
+                const int k = kbase + 16 * g + 4 * r;
+                if (k < K) {
+                    const mf4 v = mf4{o[0][r], o[1][r], o[2][r], o[3][r]};
+                    if (k < dim) *reinterpret_cast<mf4*>(da + m * dim + k) = v; else *reinterpret_cast<mf4*>(db + m * dim + (k - dim)) = v;
+                }
             }
-        }
-#pragma unroll
-        for (int r = 0; r < kMergeRows; ++r) {
-            const int64_t row = row0 + r;
-            if (row < n) { if (k < dim) da[row * dim + k] = acc[r]; else db[row * dim + (k - dim)] = acc[r]; }
         }
     }
 }
@@ -466,17 +438,16 @@ extern "C" int dygnn_merge_layer_logits(const float* a, const float* b, int64_t 
 extern "C" int dygnn_merge_layer_backward(const float* a, const float* b, int64_t n, int32_t dim, int32_t hidden, const float* fc1_w, const float* fc1_b,
                                           const float* fc2_w, const float* grad_logits, float* grad_a, float* grad_b, float* grad_fc1_w, float* grad_fc1_b,
                                           float* grad_fc2_w, float* grad_fc2_b, float* workspace, dygnn_stream_t stream) {
-    DYGNN_REQUIRE(n >= 0 && dim > 0 && hidden > 0 && dim % 4 == 0 && 2 * dim <= 512, "merge_layer_backward: bad sizes (dim: a multiple of 4, at most 256)");
+    DYGNN_REQUIRE(n >= 0 && dim > 0 && hidden > 0 && dim % 4 == 0 && hidden % 4 == 0 && hidden <= 192, "merge_layer_backward: dim and hidden must be multiples of 4, hidden <= 192");
     DYGNN_REQUIRE(a && b && fc1_w && fc1_b && fc2_w && grad_logits && grad_a && grad_b && grad_fc1_w && grad_fc1_b && grad_fc2_w && grad_fc2_b && workspace,
                   "merge_layer_backward: null pointer");
-    const size_t lds_w = (size_t)(kMergeJ * 2 * dim + 256 * kMergeJ + 8 * kMergeJ + 4) * sizeof(float), lds_x = (size_t)kMergeRows * hidden * sizeof(float);
-    DYGNN_REQUIRE(lds_w <= 64 * 1024 && lds_x <= 64 * 1024, "merge_layer_backward: dim / hidden too large");
-    hipLaunchKernelGGL(k_merge_bwd_w, dim3((unsigned)ceil_div(hidden, kMergeJ)), dim3(256), lds_w, as_stream(stream), a, b, n, dim, hidden, fc1_w, fc1_b, fc2_w,
-                       grad_logits, workspace, grad_fc1_w, grad_fc1_b, grad_fc2_w, grad_fc2_b);
-    DYGNN_LAUNCH_CHECK();
+    DYGNN_REQUIRE(((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0,
+                  "merge_layer_backward: a, b and the workspace must be 16-byte aligned");
     if (n == 0) return DYGNN_OK;
-    hipLaunchKernelGGL(k_merge_bwd_x, dim3((unsigned)ceil_div(n, (int64_t)kMergeRows)), dim3(256), lds_x, as_stream(stream), n, dim, hidden, fc1_w, workspace, grad_a,
-                       grad_b);
+    hipLaunchKernelGGL(k_merge_bwd_rows, dim3((unsigned)ceil_div(n, (int64_t)16)), dim3(256), 0, as_stream(stream), a, b, n, dim, hidden, fc1_w, fc1_b, fc2_w, grad_logits,
+                       workspace, hidden, grad_a, grad_b, grad_fc2_w, grad_fc2_b);
     DYGNN_LAUNCH_CHECK();
-    return DYGNN_OK;
+    const train::DwPair pairs[2] = {{workspace, hidden, hidden, a, dim, dim, grad_fc1_w, 2 * dim, grad_fc1_b},
+                                    {workspace, hidden, hidden, b, dim, dim, grad_fc1_w + dim, 2 * dim, nullptr}};
+    return train::dw_grouped(as_stream(stream), (int)n, pairs, 2);
 }

@@ -637,7 +637,7 @@ struct DwList {
         int ksplit = 512 / args.nitems;
         if (ksplit < 1) ksplit = 1;
         int kchunk = (((K + ksplit - 1) / ksplit) + 15) & ~15;
-        if (kchunk < 256) kchunk = 256;
+        if (kchunk < 32) kchunk = 32;            // (a short K — the link predictor's 200 rows — is still worth splitting: each 16-wide step is a DMA round trip)
         ksplit = (K + kchunk - 1) / kchunk;
         args.K = K; args.kchunk = kchunk;
         DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_grouped), hipFuncAttributeMaxDynamicSharedMemorySize, kDwLdsBytes));
@@ -646,6 +646,13 @@ struct DwList {
         return DYGNN_OK;
     }
 };
+
+int dw_grouped(hipStream_t s, int K, const DwPair* pairs, int npairs) {
+    DwList dw;
+    for (int i = 0; i < npairs; ++i) dw.add(pairs[i].A, pairs[i].lda, pairs[i].M, pairs[i].B, pairs[i].ldb, pairs[i].N, pairs[i].C, pairs[i].ldc, pairs[i].colsum);
+    if (!dw.ok) { set_error("dw_grouped: operands are not 16-byte aligned / too many problems"); return DYGNN_E_UNSUPPORTED; }
+    return dw.launch(s, K);
+}
 
 // out[n] += sum_m A[m][n]   (bias gradients): workgroup = 64 columns x a chunk of 256 rows, one atomic per column and workgroup
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ A, int lda, int64_t M, int N, float* __restrict__ out) {

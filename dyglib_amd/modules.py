@@ -27,7 +27,7 @@ class TimeEncoder(nn.Module):
 
 class _MergeFunction(torch.autograd.Function):
     """logits = fc2(relu(fc1(cat(x1, x2)))) for output_dim 1 with its backward pass on the HIP library: one launch forward
-    (dygnn_merge_layer_logits), one launch backward (dygnn_merge_layer_backward: two launches, no atomics; the hidden layer is recomputed, nothing is kept)."""
+    (dygnn_merge_layer_logits), one launch backward (dygnn_merge_layer_backward: two launches on the matrix cores; the hidden layer is recomputed, nothing is kept)."""
 
     @staticmethod
     def forward(ctx, a, b, w1, b1, w2, b2):
@@ -46,11 +46,12 @@ class _MergeFunction(torch.autograd.Function):
         g = g.reshape(-1).contiguous().float()
         da, db = torch.empty_like(a), torch.empty_like(b)
         n, hidden = a.shape[0], w1.shape[0]
-        flat = torch.empty(w1.numel() + b1.numel() + w2.numel() + 1 + n * hidden, dtype=torch.float32, device=a.device)      # gradients | workspace
+        flat = torch.zeros(w1.numel() + b1.numel() + w2.numel() + 1, dtype=torch.float32, device=a.device)      # accumulated into (atomics)
+        work = torch.empty(n * hidden, dtype=torch.float32, device=a.device)
         o1, o2, o3 = w1.numel(), w1.numel() + b1.numel(), w1.numel() + b1.numel() + w2.numel()
         _capi.check(lib.dygnn_merge_layer_backward(a.data_ptr(), b.data_ptr(), n, a.shape[1], hidden, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
                                                    g.data_ptr(), da.data_ptr(), db.data_ptr(), flat.data_ptr(), flat[o1:].data_ptr(), flat[o2:].data_ptr(),
-                                                   flat[o3:].data_ptr(), flat[o3 + 1:].data_ptr(), _capi.current_stream_ptr()))
+                                                   flat[o3:].data_ptr(), work.data_ptr(), _capi.current_stream_ptr()))
         return da, db, flat[:o1].view_as(w1), flat[o1:o2].view_as(b1), flat[o2:o3].view_as(w2), flat[o3:o3 + 1]
 
 

@@ -329,8 +329,8 @@ int dygnn_merge_layer_sigmoid(const float* a, const float* b, int64_t n, int32_t
                               const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
                               float* out, dygnn_stream_t stream);
 /* The same head for the TRAINING step (train_link_prediction.py:241-257): the logits z = MergeLayer(a, b) [n] (output_dim 1) and their
- * backward pass.  grad_logits = dL/dz [n]; grad_a, grad_b [n,dim] and the four parameter gradients are WRITTEN (no accumulation, no
- * atomics: bitwise reproducible); `workspace` = n * hidden floats.  dim must be a multiple of 4, at most 256. */
+ * backward pass.  grad_logits = dL/dz [n]; grad_a, grad_b [n,dim] are written; the four parameter gradients are ACCUMULATED into buffers the
+ * caller has zeroed; `workspace` = n * hidden floats, 16-byte aligned like a and b.  dim and hidden multiples of 4, hidden <= 192. */
 int dygnn_merge_layer_logits(const float* a, const float* b, int64_t n, int32_t dim, int32_t hidden,
                              const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
                              float* out, dygnn_stream_t stream);
