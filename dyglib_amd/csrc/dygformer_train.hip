@@ -424,7 +424,7 @@ static void launch_mm_dma(hipStream_t s, const MM& p, bool tA, bool tB, int batc
 static int colsum(hipStream_t s, const float* A, int lda, int64_t M, int N, float* out, bool accumulate = false);
 
 int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb, bool tB, float* C, int ldc, int M, int N, int K, const float* bias, float alpha,
-       float beta, int batch, int H, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, bool relu, bool c_is_zero, float* colsum_out, const int32_t* m_dev) {
+       float beta, int batch, int H, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, bool relu, bool c_is_zero, float* colsum_out, const int32_t* m_dev, bool a_kpad) {
     if (M <= 0 || N <= 0 || batch <= 0) return DYGNN_OK;
     MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh, relu ? 1 : 0, 1, K, nullptr, m_dev,
          ((reinterpret_cast<uintptr_t>(C) & 15) == 0 && ldc % 4 == 0 && sCb % 4 == 0 && sCh % 4 == 0) ? 1 : 0};
@@ -453,7 +453,9 @@ int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb,
         //  of TGAT — M ~ 10^5, N and K of 136 .. 444: 26 MFMAs per 15 LDS operand reads — ran them in the SAME time as these 64 x 64 tiles
         //  (16.5 vs 16.1 ms over a profile): with K this short a workgroup lives for 9 .. 28 k-steps and its ring fill and tile write-out,
         //  not the k-loop's MFMA density, set the pace.)
-        if (vecA && vecB && K % 4 == 0 && (!tA || M % 4 == 0) && (tB || N % 4 == 0) && !(dma_env && dma_env[0] == '0')) {
+        // a_kpad: A is k-contiguous with rows padded to a multiple of 4 floats (zeros behind K): its last float4 stays inside the row
+        const bool kok = K % 4 == 0 || (a_kpad && !tA && !tB && lda >= ((K + 3) & ~3));
+        if (vecA && vecB && kok && (!tA || M % 4 == 0) && (tB || N % 4 == 0) && !(dma_env && dma_env[0] == '0')) {
             // measured: 64 x 64 tiles with a 4-stage ring; 3 stages tie, 6 / 8 stages and 128 x 128 tiles (3 stages) lose occupancy and are slower
             launch_mm_dma<2, 2, 4>(s, p, tA, tB, batch);
             DYGNN_LAUNCH_CHECK();
@@ -487,7 +489,7 @@ int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb,
 // atomics: 64 lanes in 64 rows run 17x slower).
 // ------------------------------------------------------------------------------------------------
 struct DwProblem { const float* A; const float* B; float* C; float* colsum; int lda, ldb, ldc, M, N, ncw; };
-constexpr int kDwMaxProblems = 4 * DYGNN_MAX_LAYERS, kDwMaxItems = 32 * DYGNN_MAX_LAYERS, kDwNS = 3, kDwStage = 22 * 256, kDwLdsBytes = kDwNS * kDwStage * 4;
+constexpr int kDwMaxProblems = 4 * DYGNN_MAX_LAYERS + 4, kDwMaxItems = 32 * DYGNN_MAX_LAYERS + 16, kDwNS = 3, kDwStage = 22 * 256, kDwLdsBytes = kDwNS * kDwStage * 4;
 struct DwArgs {
     DwProblem prob[kDwMaxProblems];
     unsigned short item[kDwMaxItems];      // problem << 12 | m-group << 6 | n-chunk
@@ -622,14 +624,21 @@ struct DwList {
     int nprob = 0;
     bool ok = true;
     void add(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc, float* colsum) {
-        const bool aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0 && M % 4 == 0 && N % 4 == 0;
+        if (!try_add(A, lda, M, B, ldb, N, C, ldc, colsum)) ok = false;
+    }
+    // M need not be a multiple of 4 when A's rows are padded to one (lda >= round_up(M, 4)): the float4 that holds the last columns then stays
+    // inside the row, and outputs beyond M are never written
+    bool try_add(const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc, float* colsum) {
+        const bool aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+                             (M % 4 == 0 || lda >= ((M + 3) & ~3)) && N % 4 == 0;
         const int nch = (N + 207) / 208, ncw = (((N + nch - 1) / nch) + 3) & ~3;
         const int mg = (M + 127) / 128;
-        if (!aligned || nprob >= kDwMaxProblems || mg > 64 || nch > 64 || args.nitems + mg * nch > kDwMaxItems) { ok = false; return; }
+        if (!aligned || nprob >= kDwMaxProblems || mg > 64 || nch > 64 || args.nitems + mg * nch > kDwMaxItems) return false;
         args.prob[nprob] = DwProblem{A, B, C, colsum, lda, ldb, ldc, M, N, ncw};
         for (int x = 0; x < mg; ++x)
             for (int y = 0; y < nch; ++y) args.item[args.nitems++] = (unsigned short)(nprob << 12 | x << 6 | y);
         ++nprob;
+        return true;
     }
     int launch(hipStream_t s, int K) {
         if (nprob == 0 || K <= 0) return DYGNN_OK;
@@ -1049,12 +1058,23 @@ __global__ void k_pool_bwd(const float* __restrict__ dpooled, int64_t B, int Ts,
     dX[i] = dpooled[((int64_t)side * B + b) * D + n] / (float)(side ? T - Ts : Ts);
 }
 
+// dX0 [M][4 C] -> four channel blocks [4][M][Cp], Cp = round_up(C, 4), zeros behind C: every block is then a 16-byte-aligned operand of the
+// grouped weight-gradient launch (projection weights) and of the LDS-DMA GEMM (time / co-occurrence encoder inputs)
+__global__ void k_split_channels(const float* __restrict__ dX, int64_t M, int C, int Cp, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * M * Cp) return;
+    const int j = (int)(i % Cp);
+    const int64_t row = (i / Cp) % M;
+    const int ch = (int)(i / ((int64_t)Cp * M));
+    out[i] = j < C ? dX[row * (4 * C) + ch * C + j] : 0.f;
+}
+
 // ---- workspace -----------------------------------------------------------------------------------------------------------
 struct Plan {
     WorkspaceLayout wl;       // prefix compatible with window_lengths_device (dims, hist_len, end_pos)
     size_t ids, dts, c0, c1, lut, hid, Pn, Pe, Pt, Pc, X[DYGNN_MAX_LAYERS + 1];
     struct L { size_t xn0, m0, r0, qkv, S, P, Pd, oa, ao, x1, xn1, m1, r1, hpre, hact, f2, dF2, dH, dAo, dQKV; } layer[DYGNN_MAX_LAYERS];
-    size_t pooled, out, dX, dA, dB, dpool, dPt, dPc, dlut, total;
+    size_t pooled, out, dX, dA, dB, dXc, dpool, dPt, dPc, dlut, total;
 };
 static Plan make_plan(const Dims& d, int64_t B) {
     Plan p{};
@@ -1074,7 +1094,7 @@ static Plan make_plan(const Dims& d, int64_t B) {
         L.hpre = take(M * 4 * d.D * F); L.hact = take(M * 4 * d.D * F); L.f2 = take(M * d.D * F);
     }
     p.pooled = take((size_t)2 * B * d.D * F); p.out = take((size_t)2 * B * d.Fn * F);
-    p.dX = take(M * d.D * F); p.dA = take(M * d.D * F); p.dB = take(M * d.D * F);
+    p.dX = take(M * d.D * F); p.dA = take(M * d.D * F); p.dB = take(M * d.D * F); p.dXc = take(4 * M * ((d.C + 3) & ~3) * F);
     // operands of the weight gradients stay alive until the ONE grouped launch at the end of the backward pass (k_dw_grouped): per layer
     for (int l = 0; l < d.NL; ++l) {
         auto& L = p.layer[l];
@@ -1296,25 +1316,34 @@ extern "C" int dygnn_dygformer_backward(const dygnn_dygformer_config* cfg, const
                            dX, G(Lg.norm0_weight), G(Lg.norm0_bias));                                                          // dX is now dX_l
         DYGNN_LAUNCH_CHECK();
     }
-    // every weight gradient of the encoder layers (and its bias gradient) in one grouped split-K launch
-    if (!dw.ok) { set_error("backward: weight-gradient operands are not 16-byte aligned / too many problems"); return DYGNN_E_UNSUPPORTED; }
-    if (int rc = dw.launch(s, (int)M)) return rc;
-    // projections: X0[:, ch] = P_ch W_ch^T + b_ch
+    // projections: X0[:, ch] = P_ch W_ch^T + b_ch.  dX0 is split into channel blocks (aligned operands); the four projection weight gradients
+    // join the grouped launch where their shapes allow, the rest takes the general path
     const float* PW[4] = {w->proj_node_w, w->proj_edge_w, w->proj_time_w, w->proj_cooc_w};
     float* GW[4] = {G(grads->proj_node_w), G(grads->proj_edge_w), G(grads->proj_time_w), G(grads->proj_cooc_w)};
     float* GB[4] = {G(grads->proj_node_b), G(grads->proj_edge_b), G(grads->proj_time_b), G(grads->proj_cooc_b)};
     const size_t PM[4] = {p.Pn, p.Pe, p.Pt, p.Pc};
     const int PK[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * C};
+    const int Cp = (C + 3) & ~3;
+    float* dXc = F32(p.dXc);
+    EW(k_split_channels, 4 * M * Cp, dX, M, C, Cp, dXc);
+    bool grouped[4];
+    for (int ch = 0; ch < 4; ++ch) grouped[ch] = dw.try_add(dXc + (size_t)ch * M * Cp, Cp, C, F32(PM[ch]), PK[ch], PK[ch], GW[ch], PK[ch], GB[ch]);
+    // every weight gradient of the encoder layers and projections (and its bias gradient) in one grouped split-K launch
+    if (!dw.ok) { set_error("backward: weight-gradient operands are not 16-byte aligned / too many problems"); return DYGNN_E_UNSUPPORTED; }
+    if (int rc = dw.launch(s, (int)M)) return rc;
     for (int ch = 0; ch < 4; ++ch) {
+        if (grouped[ch]) continue;
         if (int rc = mm(s, dX + ch * C, D, true, F32(PM[ch]), PK[ch], false, GW[ch], PK[ch], C, PK[ch], (int)M, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, true, GB[ch])) return rc;     // dW_ch [C][K]
     }
     // time encoder
-    if (int rc = mm(s, dX + 2 * C, D, false, PW[2], PK[2], false, F32(p.dPt), PK[2], (int)M, PK[2], C)) return rc;
+    if (int rc = mm(s, dXc + (size_t)2 * M * Cp, Cp, false, PW[2], PK[2], false, F32(p.dPt), PK[2], (int)M, PK[2], C, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, false,
+                    nullptr, nullptr, true)) return rc;
     hipLaunchKernelGGL(k_time_bwd, dim3((unsigned)B), dim3(256), 2 * d.Ft * sizeof(float), s, F32(p.dPt), I32(p.ids), F32(p.dts), w->time_w, w->time_b, B, Ss, Sd, Ts, T,
                        d.P, d.Ft, G(grads->time_w), G(grads->time_b));
     DYGNN_LAUNCH_CHECK();
     // co-occurrence encoder
-    if (int rc = mm(s, dX + 3 * C, D, false, PW[3], PK[3], false, F32(p.dPc), PK[3], (int)M, PK[3], C)) return rc;
+    if (int rc = mm(s, dXc + (size_t)3 * M * Cp, Cp, false, PW[3], PK[3], false, F32(p.dPc), PK[3], (int)M, PK[3], C, nullptr, 1.f, 0.f, 1, 1, 0, 0, 0, 0, 0, 0, false, false,
+                    nullptr, nullptr, true)) return rc;
     DYGNN_HIP(hipMemsetAsync(F32(p.dlut), 0, (size_t)(S + 1) * C * sizeof(float), s));
     hipLaunchKernelGGL(k_cooc_bwd, dim3((unsigned)ceil_div(B, kPairsPerWg)), dim3(256), (size_t)kCoocGroups * kCoocRows * C * sizeof(float), s, F32(p.dPc),
                        I32(p.c0), I32(p.c1), B, Ss, Sd, Ts, T, d.P, C, F32(p.dlut));
