@@ -1120,6 +1120,7 @@ struct FfnBwdArgs {
     float *dF2, *dH;                             // [M][200], [M][800]
     float *dgamma, *dbeta;                       // LN1 (accumulated)
     train::Drop dr; uint32_t site_act, site_out;
+    unsigned long long* stamps;                  // diagnostic build only
 };
 __device__ __forceinline__ float gelu_grad(float v) {                       // d/dv [v Phi(v)] = Phi(v) + v phi(v)
     const float cdf = 0.5f * (1.0f + erf_as(v * 0.70710678118654752440f));
@@ -1131,6 +1132,7 @@ __global__ __launch_bounds__(512, 2) void k_ffn_bwd(const FfnBwdArgs a) {
     const int c = lane & 15, g = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * kTokWG + 16 * wave, row = row0 + c;
     const bool active = row0 < a.M, valid = row < a.M;
+    TDECL;
     WStream ws;
     ws.open(a.stream, kLdsRing, lane, wave, a.nstages);
     const float* ringl = lds + kLdsRing + lane * 4;
@@ -1163,6 +1165,7 @@ __global__ __launch_bounds__(512, 2) void k_ffn_bwd(const FfnBwdArgs a) {
     hp[1] = valid ? ldg4(hrow + 16) : zero4();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the first ring stages have landed
     __syncthreads();
+    TACC(0);
 #pragma unroll 1
     for (int p = 0; p < 25; ++p) {
         f4 dh[2];
@@ -1174,19 +1177,27 @@ __global__ __launch_bounds__(512, 2) void k_ffn_bwd(const FfnBwdArgs a) {
             hn[0] = more ? ldg4(hrow + 32 * (p + 1)) : zero4();
             hn[1] = more ? ldg4(hrow + 32 * (p + 1) + 16) : zero4();
             ffn_w1(dh, d2, dk0, dk1, ringl + ws.pos * kFrag, nullptr, g);
+            TACC(1);
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     dh[u][r] *= a.dr.mask32(sk2, (uint32_t)row * kHid + 32 * p + 16 * u + 4 * g + r) * gelu_grad(hp[u][r]);
-            if (valid) { *reinterpret_cast<f4*>(dhrow + 32 * p) = dh[0]; *reinterpret_cast<f4*>(dhrow + 32 * p + 16) = dh[1]; }
-        }
-        ws.advance(26, active ? 2 : 0);
-        if (active) {
-            ffn_w2(dxn, dh, ringl + ws.pos * kFrag);
+            // take the prefetched rows NOW, before the stores below are issued: vmcnt retires in order and the compiler does not see the ring's
+            // DMAs, so a wait for these loads placed behind the stores would also sit out the stores' whole round trip
             hp[0] = hn[0]; hp[1] = hn[1];
+            asm volatile("" : "+v"(hp[0]), "+v"(hp[1]));
         }
+        TACC(2);
         ws.advance(26);
+        TACC(3);
+        // the dhpre rows leave AFTER the stage barrier's DMA issue: at the next barrier they are the two youngest operations and stay in flight
+        // (vmcnt(2) proves the older DMAs landed), and they have both blocks of the next step to retire before a full drain
+        if (valid) { *reinterpret_cast<f4*>(dhrow + 32 * p) = dh[0]; *reinterpret_cast<f4*>(dhrow + 32 * p + 16) = dh[1]; }
+        if (active) ffn_w2(dxn, dh, ringl + ws.pos * kFrag);
+        TACC(4);
+        ws.advance(26, active ? 2 : 0);
+        TACC(5);
     }
     // LayerNorm-1 backward (x1 rows and their statistics from the forward): dx1 = dX + rstd (gy - mean(gy) - xhat mean(gy xhat)), gy = dxn gamma
     ws.fit(1);
@@ -1238,6 +1249,7 @@ __global__ __launch_bounds__(512, 2) void k_ffn_bwd(const FfnBwdArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA of this workgroup is left in flight
     __syncthreads();
+    TACC(6);
     for (int i = tid; i < 2 * kDP; i += 512) {
         const int which = i / kDP, n = i % kDP;
         float t = 0.f;
@@ -1245,6 +1257,8 @@ __global__ __launch_bounds__(512, 2) void k_ffn_bwd(const FfnBwdArgs a) {
         for (int w = 0; w < 8; ++w) t += red[(w * 2 + which) * kDP + n];
         if (n < kD) atomicAdd((which ? a.dbeta : a.dgamma) + n, t);
     }
+    TACC(7);
+    TSTORE();
 }
 
 // ================================================================================================
@@ -1391,6 +1405,7 @@ __device__ __forceinline__ void ln_backward(const f4 (&dxn)[kNT], const float* x
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};      // LDS-DMA source for rows that do not exist
 struct AttnBwdArgs {
     const float* stream; int nstages;
     int64_t B; int T;
@@ -1401,6 +1416,7 @@ struct AttnBwdArgs {
     float *dgamma, *dbeta;                       // LN0 (accumulated)
     train::Drop dr; uint32_t site_p, site_ao;
     float qscale;
+    unsigned long long* stamps;                  // diagnostic build only
 };
 template <int TPW>
 __global__ __launch_bounds__(512, 2) void k_attn_bwd(const AttnBwdArgs a) {
@@ -1416,6 +1432,7 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd(const AttnBwdArgs a) {
     const int tok = 16 * tt + c;
     const int64_t row = b * T + tok;
     const int tokbase = pi * (16 * TPW);
+    TDECL;
     WStream ws;
     ws.open(a.stream, kLdsRing, lane, wave, a.nstages);
     const float* ringl = lds + kLdsRing + lane * 4;
@@ -1446,11 +1463,27 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd(const AttnBwdArgs a) {
     const bool vec = (T & 3) == 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the first ring stages have landed (and this lane's dAo row is written)
     __syncthreads();
+    TACC(0);
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
         const float* qrow = a.qkv + row * (3 * kD) + kHD * h + 4 * g;
         float* drow = a.dQKV + row * (3 * kD) + kHD * h + 4 * g;
         const int64_t pbase = (b * 2 + h) * (int64_t)T * T;
+        // ---- K and V rows of the pair go to LDS by DMA (no registers) and this wave's Q rows (needed in phase B) into registers NOW: they land
+        // while the Wo^T product runs.  (Every wave passed stream barriers since the previous head's last reads of the K/V region.)
+        {
+            constexpr int NCH = 16 * TPW * kKV * 4 / 1024;             // 1-KiB pieces of a pair's K (or V) block: rows are contiguous in LDS
+            for (int q = tt; q < NCH; q += TPW) {
+                const int o = 1024 * q + 16 * lane, r = o / (4 * kKV), cb = (o - r * 4 * kKV) >> 2;
+                const bool on = pair_ok && r < T;
+                const float* src = a.qkv + (b * T + r) * (3 * kD) + kHD * h + cb;
+                dma_frag(on ? src + kD : g_zero16, kLdsK + tokbase * kKV + 256 * q);
+                dma_frag(on ? src + 2 * kD : g_zero16, kLdsV + tokbase * kKV + 256 * q);
+            }
+        }
+        f4 qrows[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) qrows[j] = (valid && (j < 6 || g == 0)) ? ldg4(qrow + 16 * j) : zero4();
         // ---- dOa^T = Wo[:, h]^T . dAo^T
         f4 doa[7];
 #pragma unroll
@@ -1462,18 +1495,10 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd(const AttnBwdArgs a) {
             if (F3_KSKIP) kpack(dA[kKC - 1], k0, k1);
             qkv_group(doa, dA, k0, k1, ws, ringl, active);
         }
-        // ---- K, V rows of this wave's tokens into LDS (every wave passed stream barriers since the previous head's last reads), Q^T scaled
-        f4 qa[7];
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const bool on = valid && (j < 6 || g == 0);
-            qa[j] = on ? ldg4(qrow + 16 * j) * a.qscale : zero4();
-            if (active && (j < 6 || g == 0)) {
-                *reinterpret_cast<f4*>(Kb + (tokbase + tok) * kKV + 4 * g + 16 * j) = on ? ldg4(qrow + kD + 16 * j) : zero4();
-                *reinterpret_cast<f4*>(Vb + (tokbase + tok) * kKV + 4 * g + 16 * j) = on ? ldg4(qrow + 2 * kD + 16 * j) : zero4();
-            }
-        }
+        TACC(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of K and V have landed
         __syncthreads();
+        TACC(2);
         // ---- phase A: this wave's tokens as queries
         f4 dq[7];
 #pragma unroll
@@ -1507,27 +1532,34 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd(const AttnBwdArgs a) {
                 for (int r = 0; r < 4; ++r) ds[kt][r] = pt[kt][r] * (ds[kt][r] - D) * a.qscale;
             if (g == 0) Dq[tokbase + tok] = D;
             pv_like<TPW>(dq, Kb + tokbase * kKV, ds, c, g);                    // dQ^T = K^T . dS^T (scaled)
-            if (valid) {
-#pragma unroll
-                for (int j = 0; j < 7; ++j)
-                    if (j < 6 || g == 0) *reinterpret_cast<f4*>(drow + 16 * j) = dq[j];
-            }
         }
-        __syncthreads();                             // every wave is done with K and V
-        // ---- Q (unscaled) and dOa rows over K and V; this wave's V^T tiles (its tokens as keys)
-        f4 vt[7];
+        f4 vt[7];                                    // this wave's V^T tiles for phase B, from its own rows while they are still in LDS
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const bool on = valid && (j < 6 || g == 0);
-            vt[j] = on ? ldg4(qrow + 2 * kD + 16 * j) : zero4();
-            if (active && (j < 6 || g == 0)) {
-                *reinterpret_cast<f4*>(Kb + (tokbase + tok) * kKV + 4 * g + 16 * j) = on ? ldg4(qrow + 16 * j) : zero4();
-                *reinterpret_cast<f4*>(Vb + (tokbase + tok) * kKV + 4 * g + 16 * j) = doa[j];
-            }
+        for (int j = 0; j < 7; ++j) vt[j] = (active && (j < 6 || g == 0)) ? lds4(Vb + (tokbase + tok) * kKV + 4 * g + 16 * j) : zero4();
+        TACC(3);
+        __syncthreads();                             // every wave is done with K and V
+        // ---- Q (unscaled, from the registers loaded above) and dOa rows over K and V; this wave's own V rows (its tokens as keys) were read
+        // back from LDS before the barrier: the exchange touches no global memory
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                if (j < 6 || g == 0) {
+                    *reinterpret_cast<f4*>(Kb + (tokbase + tok) * kKV + 4 * g + 16 * j) = qrows[j];
+                    *reinterpret_cast<f4*>(Vb + (tokbase + tok) * kKV + 4 * g + 16 * j) = doa[j];
+                }
         }
         __syncthreads();
+        TACC(4);
         // dxn0 += Wq[h]^T . dQ^T while the exchange settles (stream order: Wo^T, Wq^T, Wv^T, Wk^T)
         proj_t(dxn, dq, ws, ringl, active);
+        // the row stores of dQ (and of dV, dK below) come AFTER the loads that follow their computation: a load behind a store waits for the
+        // store's round trip (in-order vmcnt)
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                if (j < 6 || g == 0) *reinterpret_cast<f4*>(drow + 16 * j) = dq[j];
+        }
+        TACC(5);
         // ---- phase B: this wave's tokens as keys; tiles [query rows 16 qt + 4 g + r][own key column c]
         f4 dv[7], dk[7];
 #pragma unroll
@@ -1551,23 +1583,20 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd(const AttnBwdArgs a) {
                         ds2[qt][r] = pv * (dp - Dq[tokbase + q]) * a.qscale;
                     }
                 pv_like<TPW>(dv, Vb + tokbase * kKV, pd2, c, g);               // dV^T = dOa^T . Pd
-                if (valid) {
-#pragma unroll
-                    for (int j = 0; j < 7; ++j)
-                        if (j < 6 || g == 0) *reinterpret_cast<f4*>(drow + 2 * kD + 16 * j) = dv[j];
-                }
             }
+            TACC(6);
             proj_t(dxn, dv, ws, ringl, active);
-            if (active) {
-                pv_like<TPW>(dk, Kb + tokbase * kKV, ds2, c, g);               // dK^T = Q^T . dS (scaled)
-                if (valid) {
-#pragma unroll
-                    for (int j = 0; j < 7; ++j)
-                        if (j < 6 || g == 0) *reinterpret_cast<f4*>(drow + kD + 16 * j) = dk[j];
-                }
-            }
+            TACC(7);
+            if (active) pv_like<TPW>(dk, Kb + tokbase * kKV, ds2, c, g);       // dK^T = Q^T . dS (scaled)
         }
+        TACC(8);
         proj_t(dxn, dk, ws, ringl, active);
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                if (j < 6 || g == 0) { *reinterpret_cast<f4*>(drow + 2 * kD + 16 * j) = dv[j]; *reinterpret_cast<f4*>(drow + kD + 16 * j) = dk[j]; }
+        }
+        TACC(9);
     }
     // ---- LayerNorm-0 backward
     ws.fit(1);
@@ -1583,6 +1612,8 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd(const AttnBwdArgs a) {
         for (int w = 0; w < 8; ++w) t += lds[(w * 2 + which) * kDP + n];
         if (n < kD) atomicAdd((which ? a.dbeta : a.dgamma) + n, t);
     }
+    TACC(10);
+    TSTORE();
 }
 
 // ================================================================================================
@@ -1997,6 +2028,9 @@ int ffn_backward_fused3(const Dims& d, const PackedLayout& pl, const float* pack
     a.stream = packed + pl.fused3 + f.bwd[l]; a.nstages = f.bwd_nstages;
     a.M = M; a.dX = dX; a.hpre = hpre; a.x1 = x1; a.m1 = m1; a.r1 = r1; a.dF2 = dF2; a.dH = dH; a.dgamma = dgamma; a.dbeta = dbeta;
     a.dr = dr; a.site_act = (uint32_t)(4 * l + 2); a.site_out = (uint32_t)(4 * l + 3);
+#ifdef DYGNN_STAMPS
+    if (const char* sp = getenv("DYGNN_STAMPS_FFN")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0));
+#endif
     DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffn_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     hipLaunchKernelGGL(k_ffn_bwd, dim3((unsigned)ceil_div(M, (int64_t)kTokWG)), dim3(512), kLdsBytes, s, a);
     DYGNN_LAUNCH_CHECK();
@@ -2015,6 +2049,9 @@ int attn_backward_fused3(const Dims& d, const PackedLayout& pl, const float* pac
     a.B = B; a.T = T; a.dX = dX; a.X = X; a.m0 = m0; a.r0 = r0; a.qkv = qkv; a.P = P; a.Pd = Pd; a.dAo = dAo; a.dQKV = dQKV; a.dgamma = dgamma; a.dbeta = dbeta;
     a.dr = dr; a.site_p = (uint32_t)(4 * l + 0); a.site_ao = (uint32_t)(4 * l + 1);
     a.qscale = (float)sqrt(1.0 / (double)d.hd);
+#ifdef DYGNN_STAMPS
+    if (const char* sp = getenv("DYGNN_STAMPS_ATTN")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0));
+#endif
     DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     if (T <= 64) hipLaunchKernelGGL(k_attn_bwd<4>, dim3((unsigned)((B + 1) / 2)), dim3(512), kLdsBytes, s, a);
