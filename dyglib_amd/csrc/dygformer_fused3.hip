@@ -420,10 +420,15 @@ __device__ __forceinline__ void residual_dropped(f4 (&x)[kNT], const float* xin,
     float* dst = out ? out + row * kD + 4 * g : nullptr;
     // (all thirteen row loads in flight first would expose one latency instead of thirteen, but next to the two live register sets it spills:
     //  measured 10 % slower)
+    constexpr int RQ = 1;                                    // row tiles in flight ahead of the one being finished
+    f4 rq[RQ];
+#pragma unroll
+    for (int u = 0; u < RQ; ++u) rq[u] = (valid && (u < 12 || g < 2)) ? ldg4(src + 16 * u) : zero4();
 #pragma unroll
     for (int i = 0; i < kNT; ++i) {
         const bool on = valid && (i < 12 || g < 2);          // rows 200 .. 207 do not exist
-        f4 v = on ? ldg4(src + 16 * i) : zero4();
+        f4 v = rq[i % RQ];
+        if (i + RQ < kNT) rq[i % RQ] = (valid && (i + RQ < 12 || g < 2)) ? ldg4(src + 16 * (i + RQ)) : zero4();
         const f4 bv = lds4(bias_lds + 16 * i);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (y[i][r] + bv[r]) * dr.mask32(sk, e0 + 16 * i + r);      // rows >= 200: y and the bias are zero
