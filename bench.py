@@ -593,6 +593,7 @@ def bench_train(dev, steps: int = 20, warmup: int = 8, separate_calls: bool = Fa
         return cache[i]
 
     def step(i):
+        nonlocal separate_calls
         src, dst, neg, t = batch(i)
         if separate_calls:      # the reference's call pattern (train_link_prediction.py:229-239), two passes
             ps, pd = model.compute_src_dst_node_temporal_embeddings(src, dst, t)
@@ -623,6 +624,20 @@ def bench_train(dev, steps: int = 20, warmup: int = 8, separate_calls: bool = Fa
            "roofline": {"bound": "mfma", "achieved": round(flop / sec / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(flop / sec / (PEAK_F32_MFMA_TFLOPS * 1e12), 4), "traffic": None, "flop_per_step": flop,
                         "note": "3 x the forward's algorithmic flops over the whole step time (host work, optimizer and link predictor included)"}}
+    if not separate_calls:
+        # the reference's own call pattern (train_link_prediction.py:229-239: two calls per step) beside the one-pass form, same model state
+        separate_calls = True
+        for i in range(3):
+            step(warmup + steps + i)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(10):
+            step(warmup + steps + 3 + i)
+        torch.cuda.synchronize(dev)
+        sec2 = (time.perf_counter() - t1) / 10
+        separate_calls = False
+        out["two_calls_per_step"] = {"value": round(B / sec2, 1), "unit": "edges/s", "ms_per_step": round(sec2 * 1e3, 4), "steps": 10,
+                                     "what": "the same step with the reference's two separate forward calls (every kernel on half the grid)"}
     if cpu_budget_s > 0:
         from oracle import dygformer_oracle as orc
         torch.set_num_threads(cpu_threads())

@@ -158,3 +158,35 @@ def test_hip_mid_size_batches_against_oracle():
                 close(got.cpu().numpy(), want.numpy(), f"tgn mid-size batch {i} {what}", label=f"tgn mid-size (B=200, k=10, 12 batches) {what}")
     close(m.memory_bank.node_memories.data.cpu().numpy(), st.M.numpy(), "tgn mid-size memory after 12 batches")
     close(m.memory_bank.node_last_updated_times.data.cpu().numpy(), st.U.numpy(), "tgn mid-size last update after 12 batches")
+
+
+@pytest.mark.gpu
+def test_joint_step_equals_the_four_array_form():
+    """compute_step_embeddings_joint (the step as ONE batch [positives ; negatives], no per-step concatenation kernels) returns the rows of
+    compute_step_embeddings and leaves the same memory bank (MemoryModel.py:87-168 over evaluate_models_utils.py:85-107)."""
+    import numpy as np
+    import torch
+    from dyglib_amd import MemoryModel, get_neighbor_sampler
+    c = gc.build_tgn_case("tgn_bip_l1_k10")
+    cfg, d, dev = c["tgn_cfg"], c["data"], "cuda:0"
+
+    def build():
+        sampler = get_neighbor_sampler(d, "recent", seed=1, device=dev)
+        m = MemoryModel(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"], model_name="TGN", num_layers=cfg["num_layers"],
+                        num_heads=cfg["num_heads"], dropout=0.1, device=dev)
+        sd = m.state_dict(); sd.update({k: torch.from_numpy(v) for k, v in c["tgn_params"].items()}); m.load_state_dict(sd)
+        m = m.to(dev).eval()
+        m.memory_bank.__init_memory_bank__()
+        return m
+
+    four, joint = build(), build()
+    k = cfg["num_neighbors"]
+    with torch.no_grad():
+        for b in c["tgn_batches"]:
+            n = len(b["src"])
+            ps, pd, ns, nd = four.compute_step_embeddings(b["src"], b["dst"], b["src"], b["neg"], b["t"], b["eid"], num_neighbors=k)
+            js, jd = joint.compute_step_embeddings_joint(np.concatenate([b["src"], b["src"]]), np.concatenate([b["dst"], b["neg"]]), np.concatenate([b["t"], b["t"]]),
+                                                         b["eid"], n, num_neighbors=k)
+            assert torch.equal(js[:n], ps) and torch.equal(jd[:n], pd) and torch.equal(js[n:], ns) and torch.equal(jd[n:], nd)
+    assert torch.equal(four.memory_bank.node_memories, joint.memory_bank.node_memories)
+    assert torch.equal(four.memory_bank.msg, joint.memory_bank.msg) and torch.equal(four.memory_bank.has_msg, joint.memory_bank.has_msg)

@@ -207,3 +207,63 @@ def test_merge_layer_autograd_matches_the_cpu_module(n):
     close(bh.grad.cpu().numpy(), br.grad.numpy().astype(np.float32), f"merge d input_2 n={n}", label="MergeLayer input gradients")
     for (k, ph), (_, pr) in zip(hip.named_parameters(), ref.named_parameters()):
         close_scaled(ph.grad.cpu().numpy(), pr.grad.numpy().astype(np.float32), f"merge grad {k} n={n}", label="MergeLayer parameter gradients (scaled bar)")
+
+
+@pytest.mark.parametrize("name", ["bip_p2_l64", "bip_p8_l512"])
+def test_fused_training_kernels_match_the_product_by_product_path_with_dropout(name, monkeypatch):
+    """The fused training forward / backward kernels (k_dygformer_fused3<.., true>, k_ffn_bwd, k_attn_bwd) against the product-by-product path
+    (DYGNN_TRAIN_UNFUSED=1: one GEMM / row kernel per reference op) WITH dropout on and the same seed: both draw their masks from the same
+    counter-based hash, so embeddings and every parameter gradient must agree to fp32 rounding (models/DyGFormer.py:418-461 in train mode)."""
+    c = gc.build_case(name)
+    model, _ = build_model(c)
+    model.train()
+    model._fixed_dropout_seed = 4321
+    G1, G2 = (torch.from_numpy(g).cuda() for g in _loss_weights(c))
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        s, t = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
+        ((s * G1).sum() + (t * G2).sum()).backward()
+        return s.detach().clone(), t.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    fs, ft, fg = run()
+    monkeypatch.setenv("DYGNN_TRAIN_UNFUSED", "1")
+    us, ut, ug = run()
+    monkeypatch.delenv("DYGNN_TRAIN_UNFUSED")
+    assert not torch.equal(fs, torch.zeros_like(fs))
+    close(fs.cpu().numpy(), us.cpu().numpy(), f"fused vs unfused train forward {name} src", label="fused vs product-by-product training path, embeddings (dropout on)")
+    close(ft.cpu().numpy(), ut.cpu().numpy(), f"fused vs unfused train forward {name} dst", label="fused vs product-by-product training path, embeddings (dropout on)")
+    for k in fg:
+        close_scaled(fg[k].cpu().numpy(), ug[k].cpu().numpy(), f"fused vs unfused grad {name} {k}", label="fused vs product-by-product training path, gradients (dropout on, scaled bar)")
+
+
+def test_in_place_weight_refresh_equals_a_full_pack():
+    """dygnn_dygformer_repack (launches only, after an optimizer step) leaves the same kernel-ready copy as dygnn_dygformer_pack: a model whose
+    weights were changed in place — through the training path (fragment streams only) and through the inference path (everything) — answers
+    like a freshly built model with the same weights."""
+    c = gc.build_case("bip_p2_l64")
+    model, _ = build_model(c)
+    with torch.no_grad():
+        model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])          # full pack
+        for p in model.parameters():
+            p.mul_(1.01)                                                                         # same addresses, new values
+    model.train(); model.dropout = 0.0
+    ts, tt = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])     # training path: pack or repack(fused_only)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(0.99)
+    ts2, _ = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])     # in-place change between two training calls: repack(fused_only)
+    model.eval()
+    with torch.no_grad():
+        es, et = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(1.02)
+        es2, et2 = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])   # inference path after an in-place change: full repack
+    fresh, _ = build_model(c)
+    fresh.load_state_dict(model.state_dict())
+    with torch.no_grad():
+        fs, ft = fresh.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
+    assert torch.equal(es2, fs) and torch.equal(et2, ft)
+    close(ts2.detach().cpu().numpy(), es.cpu().numpy(), "train-path (p=0) after fused-only refresh vs inference after full refresh", label="in-place weight refresh")
+    assert not torch.equal(ts.detach(), ts2.detach())
