@@ -210,6 +210,7 @@ struct WStream {
     const float* gsrc;    // stream base + lane*4 (per lane)
     int ring;             // LDS ring: float offset into the dynamic LDS array (wave-uniform)
     int wave, nstages;
+    int nw;               // waves of the workgroup (8; 4 in the one-pair-per-workgroup kernels for small batches): they split a stage's 13 fragments
     int pos;              // ring slot of the next fragment
     int instage;          // fragments consumed of the current stage
     int issued;           // stages whose DMA this wave has issued
@@ -217,12 +218,15 @@ struct WStream {
         if (s < nstages) {
             const float* srcp = gsrc + (size_t)s * (kStage * kFrag);
             const int dst = ring + (s & 3) * (kStage * kFrag);
-            dma_frag(srcp + wave * kFrag, dst + wave * kFrag);
-            if (wave + 8 < kStage) dma_frag(srcp + (wave + 8) * kFrag, dst + (wave + 8) * kFrag);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = wave + u * nw;
+                if (f < kStage) dma_frag(srcp + f * kFrag, dst + f * kFrag);
+            }
         }
     }
-    __device__ __forceinline__ void open(const float* stream, int ring_, int lane, int wave_, int nstages_) {
-        gsrc = stream + lane * 4; ring = ring_; wave = wave_; nstages = nstages_;
+    __device__ __forceinline__ void open(const float* stream, int ring_, int lane, int wave_, int nstages_, int nw_ = 8) {
+        gsrc = stream + lane * 4; ring = ring_; wave = wave_; nstages = nstages_; nw = nw_;
         pos = 0; instage = 0; issued = 4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) issue(s);
@@ -442,10 +446,14 @@ __device__ __forceinline__ void residual_dropped(f4 (&x)[kNT], const float* xin,
 // TR = false: inference.  TR = true: the training forward — dropout at the reference's four sites per layer and every
 // activation the backward pass reads written to HBM as dense rows (a.tr); the residual stream is re-read from those rows after the
 // attention and the FFN block instead of being kept in registers next to the separate accumulators the dropout needs.
-template <int TPW, bool TR>
-__global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
-    constexpr int NP = 8 / TPW;                  // pairs per workgroup
-    constexpr int PT = 512 / NP;                 // threads per pair
+// NW = waves per workgroup: 8 (two pairs of <= 64 tokens, or one of <= 128), or 4 = ONE pair of <= 64 tokens per workgroup, for calls of at most 256
+// pairs (the reference's own 200-pair call: 100 eight-wave workgroups would leave 156 CUs idle and run two waves per SIMD on the rest; 200
+// four-wave workgroups give every wave a matrix pipe of its own)
+template <int TPW, bool TR, int NW = 8>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_dygformer_fused3(const Args a) {
+    constexpr int NP = NW / TPW;                 // pairs per workgroup
+    constexpr int PT = 64 * NW / NP;             // threads per pair
+    constexpr int NTHR = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -484,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
     // ---- weights start moving at once: the first four stages of the layer stream into the ring, the first slab of
     // projection fragments into the K/V region behind the window arrays (all of it lands during the window phase)
     WStream ws;
-    if (!a.slab_in_ring) ws.open(a.stream, kLdsRing, lane, wave, a.nstages);
+    if (!a.slab_in_ring) ws.open(a.stream, kLdsRing, lane, wave, a.nstages, NW);
     const float* ringl = lds + kLdsRing + lane * 4;
     const int slab_off = a.slab_in_ring ? kLdsRing : a.scr_floats;
     const float* slabl = lds + slab_off + lane * 4;
@@ -492,11 +500,11 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
     auto load_slab = [&](int k) {
         const int f0 = k * slab_frags;
         const int n = a.proj_frags - f0 < slab_frags ? a.proj_frags - f0 : slab_frags;
-        for (int f = wave; f < n; f += 8) dma_frag(a.projw + (size_t)(f0 + f) * kFrag + lane * 4, slab_off + f * kFrag);
+        for (int f = wave; f < n; f += NW) dma_frag(a.projw + (size_t)(f0 + f) * kFrag + lane * 4, slab_off + f * kFrag);
     };
     load_slab(0);
     float* tws = lds + kLdsMisc + kMiscFloats;      // time-encoder w | b
-    for (int i = tid; i < 2 * a.Ft; i += 512) tws[i] = i < a.Ft ? a.time_w[i] : a.time_b[i - a.Ft];
+    for (int i = tid; i < 2 * a.Ft; i += NTHR) tws[i] = i < a.Ft ? a.time_w[i] : a.time_b[i - a.Ft];
 
     // ---- windows (pad_sequences, DyGFormer.py:228-245): per-pair arrays in the (still unused) K/V region.
     // src positions at [0, Ss), dst positions at [SsA, SsA + Sd); alignment gaps hold id -1 (matches nothing).
@@ -737,7 +745,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
         __syncthreads();
     }
     // K, V and the slack behind them: rows of absent tokens are read as MFMA operands and must be finite
-    for (int i = tid; i < kLdsRing / 4; i += 512) reinterpret_cast<f4*>(lds)[i] = zero4();
+    for (int i = tid; i < kLdsRing / 4; i += NTHR) reinterpret_cast<f4*>(lds)[i] = zero4();
     tap_store<TPW>(x, a.tap_enc, b, a.Tmax, T, tt, c, g);
 
     float* Kb = lds + kLdsK;
@@ -747,14 +755,14 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
     const bool tokv = pair_ok && 16 * tt + c < T;
 
     if (a.slab_in_ring) {        // the ring was the projection slab until now: start the layer stream (one exposed DMA latency).  Outside the
-        ws.open(a.stream, kLdsRing, lane, wave, a.nstages);      // layer loop: inside it the compiler kept the eight DMA addresses live (spilled)
+        ws.open(a.stream, kLdsRing, lane, wave, a.nstages, NW);  // layer loop: inside it the compiler kept the eight DMA addresses live (spilled)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     for (int l = 0; l < a.NL; ++l) {
         const LayerP& W = a.layer[l];
         TACC(T_MISC);
         float* b1s = misc + kMiscB1 + (l & 1) * kHid;
-        for (int i = tid; i < kHid; i += 512) b1s[i] = W.b1[i];
+        for (int i = tid; i < kHid; i += NTHR) b1s[i] = W.b1[i];
         if (l == 0) __syncthreads();     // the re-zeroing of K/V above is complete before the first K/V rows are written
 
         f4 xn[kNT];
@@ -1090,7 +1098,7 @@ __global__ __launch_bounds__(512, 2) void k_dygformer_fused3(const Args a) {
         // output layer on the matrix cores: out^T[j][col] = sum_k W[j][k] mean[col][k] + b[j]; wave w owns output tiles w, w+8, ...
         // (each fragment is used by one wave only, so they come straight from global memory, all 13 of a tile in flight)
         const int ntile = (a.Fn + 15) >> 4;
-        for (int jt = wave; jt < ntile; jt += 8) {
+        for (int jt = wave; jt < ntile; jt += NW) {
             f4 fa[kKC];
 #pragma unroll
             for (int kc = 0; kc < kKC; ++kc) fa[kc] = ldg4(a.outfrag + ((size_t)jt * kKC + kc) * kFrag + lane * 4);
@@ -1133,15 +1141,16 @@ __device__ __forceinline__ float gelu_grad(float v) {                       // d
     const float cdf = 0.5f * (1.0f + erf_as(v * 0.70710678118654752440f));
     return fmaf(v * 0.39894228040143267794f, __expf(-0.5f * v * v), cdf);
 }
-__global__ __launch_bounds__(512, 2) void k_ffn_bwd(const FfnBwdArgs a) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_ffn_bwd(const FfnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * kTokWG + 16 * wave, row = row0 + c;
+    const int64_t row0 = (int64_t)blockIdx.x * (16 * NW) + 16 * wave, row = row0 + c;
     const bool active = row0 < a.M, valid = row < a.M;
     TDECL;
     WStream ws;
-    ws.open(a.stream, kLdsRing, lane, wave, a.nstages);
+    ws.open(a.stream, kLdsRing, lane, wave, a.nstages, NW);
     const float* ringl = lds + kLdsRing + lane * 4;
     // dF2^T = (dX o mask3)^T: the B operand of every W2^T product of the layer
     f4 d2[kNT];
@@ -1257,11 +1266,11 @@ __global__ __launch_bounds__(512, 2) void k_ffn_bwd(const FfnBwdArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA of this workgroup is left in flight
     __syncthreads();
     TACC(6);
-    for (int i = tid; i < 2 * kDP; i += 512) {
+    for (int i = tid; i < 2 * kDP; i += 64 * NW) {
         const int which = i / kDP, n = i % kDP;
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) t += red[(w * 2 + which) * kDP + n];
+        for (int w = 0; w < NW; ++w) t += red[(w * 2 + which) * kDP + n];
         if (n < kD) atomicAdd((which ? a.dbeta : a.dgamma) + n, t);
     }
     TACC(7);
@@ -1428,9 +1437,9 @@ struct AttnBwdArgs {
     float qscale;
     unsigned long long* stamps;                  // diagnostic build only
 };
-template <int TPW>
-__global__ __launch_bounds__(512, 2) void k_attn_bwd(const AttnBwdArgs a) {
-    constexpr int NP = 8 / TPW;
+template <int TPW, int NW = 8>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_attn_bwd(const AttnBwdArgs a) {
+    constexpr int NP = NW / TPW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pi = wave / TPW, tt = wave % TPW;
@@ -1444,13 +1453,13 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd(const AttnBwdArgs a) {
     const int tokbase = pi * (16 * TPW);
     TDECL;
     WStream ws;
-    ws.open(a.stream, kLdsRing, lane, wave, a.nstages);
+    ws.open(a.stream, kLdsRing, lane, wave, a.nstages, NW);
     const float* ringl = lds + kLdsRing + lane * 4;
     float* Kb = lds + kLdsK;
     float* Vb = lds + kLdsV;
     float* Dq = lds + kLdsMisc;                  // [128] D of every query of the workgroup
-    for (int i = tid; i < kLdsRing / 4; i += 512) reinterpret_cast<f4*>(lds)[i] = zero4();      // rows of absent tokens are MFMA operands: finite
-    if (tid < kTokWG) Dq[tid] = 0.f;
+    for (int i = tid; i < kLdsRing / 4; i += 64 * NW) reinterpret_cast<f4*>(lds)[i] = zero4();      // rows of absent tokens are MFMA operands: finite
+    for (int i = tid; i < kTokWG; i += 64 * NW) Dq[i] = 0.f;
     // dAo = dX o mask1 (DyGFormer.py:456), as rows: the operand of the out-projection's weight gradient and of the dOa products below
     {
         const uint32_t sk = a.dr.site_key(a.site_ao), e0 = (uint32_t)row * kD + 4 * g;
@@ -1615,11 +1624,11 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd(const AttnBwdArgs a) {
     ln_backward(dxn, a.X, a.m0, a.r0, lds + kLdsRing + ws.pos * kFrag + 4 * g, a.dX, row, valid, lds, wave, c, g);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int i = tid; i < 2 * kDP; i += 512) {
+    for (int i = tid; i < 2 * kDP; i += 64 * NW) {
         const int which = i / kDP, n = i % kDP;
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) t += lds[(w * 2 + which) * kDP + n];
+        for (int w = 0; w < NW; ++w) t += lds[(w * 2 + which) * kDP + n];
         if (n < kD) atomicAdd((which ? a.dbeta : a.dgamma) + n, t);
     }
     TACC(10);
@@ -1973,6 +1982,10 @@ int pack_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_wei
     return v3::pack(d, pl, w, packed, s, reuse_desc);
 }
 
+// calls of at most this many pairs run one pair per four-wave workgroup (see k_dygformer_fused3): one round on the 256 CUs
+constexpr int64_t kSmallBatchPairs = 256;
+static bool small_off() { static const bool off = [] { const char* e = getenv("DYGNN_SMALL_BATCH_KERNELS"); return e && e[0] == '0'; }(); return off; }
+
 static int fused3_args(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_weights* w, const float* packed, const dygnn_csr* csr,
                        const float* node_feat, const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t B, int64_t G,
                        float* out_src, float* out_dst, char* ws, const WorkspaceLayout& wl, const dygnn_dygformer_taps* taps, v3::Args& a, v3::PackLayout3& f) {
@@ -2021,7 +2034,10 @@ int forward_fused3(const Dims& d, const PackedLayout& pl, const dygnn_dygformer_
     DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     if (taps && taps->ev_kernel_start) DYGNN_HIP(hipEventRecord(static_cast<hipEvent_t>(taps->ev_kernel_start), s));
     a.pair_stride = (f.np == 2 && pair_stride > 0) ? pair_stride : 0;      // one pair per workgroup (128 tokens): nothing to share inside a workgroup
-    if (f.np == 2) hipLaunchKernelGGL((k_dygformer_fused3<4, false>), dim3((unsigned)(a.pair_stride ? a.pair_stride : (B + 1) / 2)), dim3(512), kLdsBytes, s, a);
+    if (f.np == 2 && a.pair_stride == 0 && B <= kSmallBatchPairs && !small_off()) {      // a small call: one pair per four-wave workgroup
+        DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<4, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        hipLaunchKernelGGL((k_dygformer_fused3<4, false, 4>), dim3((unsigned)B), dim3(256), kLdsBytes, s, a);
+    } else if (f.np == 2) hipLaunchKernelGGL((k_dygformer_fused3<4, false>), dim3((unsigned)(a.pair_stride ? a.pair_stride : (B + 1) / 2)), dim3(512), kLdsBytes, s, a);
     else hipLaunchKernelGGL((k_dygformer_fused3<8, false>), dim3((unsigned)B), dim3(512), kLdsBytes, s, a);
     DYGNN_LAUNCH_CHECK();
     if (taps && taps->ev_kernel_stop) DYGNN_HIP(hipEventRecord(static_cast<hipEvent_t>(taps->ev_kernel_stop), s));
@@ -2041,8 +2057,13 @@ int ffn_backward_fused3(const Dims& d, const PackedLayout& pl, const float* pack
 #ifdef DYGNN_STAMPS
     if (const char* sp = getenv("DYGNN_STAMPS_FFN")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0));
 #endif
-    DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffn_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    hipLaunchKernelGGL(k_ffn_bwd, dim3((unsigned)ceil_div(M, (int64_t)kTokWG)), dim3(512), kLdsBytes, s, a);
+    if (M <= (int64_t)kSmallBatchPairs * 64 && !small_off()) {
+        DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffn_bwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        hipLaunchKernelGGL(k_ffn_bwd<4>, dim3((unsigned)ceil_div(M, (int64_t)64)), dim3(256), kLdsBytes, s, a);
+    } else {
+        DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffn_bwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        hipLaunchKernelGGL(k_ffn_bwd<8>, dim3((unsigned)ceil_div(M, (int64_t)kTokWG)), dim3(512), kLdsBytes, s, a);
+    }
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }
@@ -2064,7 +2085,10 @@ int attn_backward_fused3(const Dims& d, const PackedLayout& pl, const float* pac
 #endif
     DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    if (T <= 64) hipLaunchKernelGGL(k_attn_bwd<4>, dim3((unsigned)((B + 1) / 2)), dim3(512), kLdsBytes, s, a);
+    if (T <= 64 && B <= kSmallBatchPairs && !small_off()) {
+        DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        hipLaunchKernelGGL((k_attn_bwd<4, 4>), dim3((unsigned)B), dim3(256), kLdsBytes, s, a);
+    } else if (T <= 64) hipLaunchKernelGGL(k_attn_bwd<4>, dim3((unsigned)((B + 1) / 2)), dim3(512), kLdsBytes, s, a);
     else hipLaunchKernelGGL(k_attn_bwd<8>, dim3((unsigned)B), dim3(512), kLdsBytes, s, a);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
@@ -2089,7 +2113,10 @@ int forward_fused3_train(const Dims& d, const PackedLayout& pl, const dygnn_dygf
 #endif
     DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    if (f.np == 2) hipLaunchKernelGGL((k_dygformer_fused3<4, true>), dim3((unsigned)((B + 1) / 2)), dim3(512), kLdsBytes, s, a);
+    if (f.np == 2 && B <= kSmallBatchPairs && !small_off()) {
+        DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dygformer_fused3<4, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        hipLaunchKernelGGL((k_dygformer_fused3<4, true, 4>), dim3((unsigned)B), dim3(256), kLdsBytes, s, a);
+    } else if (f.np == 2) hipLaunchKernelGGL((k_dygformer_fused3<4, true>), dim3((unsigned)((B + 1) / 2)), dim3(512), kLdsBytes, s, a);
     else hipLaunchKernelGGL((k_dygformer_fused3<8, true>), dim3((unsigned)B), dim3(512), kLdsBytes, s, a);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
