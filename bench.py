@@ -477,6 +477,16 @@ def bench_tgat(dev, steps: int = 64, warmup: int = 3, fuse_steps: int = 32, edge
     return out
 
 
+def _prime_gpu(dev, seconds: float = 0.4) -> None:
+    """Unrelated GPU work (fp32 matmuls) for `seconds`: brings the clocks up before a short timed region that follows host-only work."""
+    a = torch.randn(2048, 2048, device=dev)
+    t = time.perf_counter()
+    while time.perf_counter() - t < seconds:
+        for _ in range(8):
+            a = (a @ a) * 1e-3
+        torch.cuda.synchronize(dev)
+
+
 def bench_tgn(dev, steps: int = 100, warmup: int = 60, cpu_budget_s: float = 10.0, cpu_max_steps: int = 30, two_calls: bool = False) -> dict:
     """BASELINE config 5: TGN link-prediction forward on a MOOC-shaped synthetic graph (7,047 + 97 nodes, 411,749 edges, 4 non-zero
     edge-feature columns), k = 10, 1 layer, batch 200, batches strictly in chronological order from interaction 0: negative call +
@@ -514,6 +524,7 @@ def bench_tgn(dev, steps: int = 100, warmup: int = 60, cpu_budget_s: float = 10.
             p = merge.link_probabilities(se, de)
             return p[:B], p[B:]
     model.memory_bank.__init_memory_bank__()
+    _prime_gpu(dev)               # the 100 timed steps are 17 ms of GPU work: without this they would run inside the clock ramp after the host-only setup
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize(dev)
@@ -610,15 +621,27 @@ def bench_train(dev, steps: int = 20, warmup: int = 8, separate_calls: bool = Fa
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize(dev)
+    # clock ramp: after seconds of host-only work (the previous legs' CPU baselines, this leg's graph construction) the first few hundred
+    # milliseconds of GPU work run at a fraction of the sustained clocks (measured: 7.5 instead of 2.8 ms per step over the first 150 ms);
+    # untimed steps until 0.5 s of GPU activity have passed, like the headline's priming launches
+    t_prime = time.perf_counter()
+    while time.perf_counter() - t_prime < 0.5:
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()
     for i in range(steps):
         loss = step(warmup + i)
+    e1.record()
     torch.cuda.synchronize(dev)
     sec = (time.perf_counter() - t0) / steps
+    gpu_ms = e0.elapsed_time(e1) / steps          # main-stream span: equals the wall time when the GPU, not the host, sets the pace
     # forward + backward = 3x the forward's algorithmic flops (each product has two gradient products): 3 * 2B pairs * 137.2 MFLOP
     flop = 3 * 2 * B * flops_per_pair(L, L, P)
     out = {"metric": "edges/sec (link-prediction TRAIN step: fwd pos+neg, bwd, Adam) DyGFormer Wikipedia-shaped", "value": round(B / sec, 1),
-           "unit": "edges/s", "ms_per_step": round(sec * 1e3, 4), "steps": steps, "warmup": warmup, "dropout": 0.1, "final_loss": round(float(loss.detach()), 4),
+           "unit": "edges/s", "ms_per_step": round(sec * 1e3, 4), "gpu_stream_ms_per_step": round(gpu_ms, 4), "steps": steps, "warmup": warmup, "priming": "0.5 s of untimed steps (clock ramp)", "dropout": 0.1, "final_loss": round(float(loss.detach()), 4),
            "config": {"workload": "DyGFormer training step, synthetic wikipedia-shaped graph, L=64, P=2, batch=200, dropout 0.1, Adam",
                       "calls": "two calls" if separate_calls else "pos+neg as one pass"},
            "roofline": {"bound": "mfma", "achieved": round(flop / sec / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
