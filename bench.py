@@ -624,8 +624,9 @@ def bench_train(dev, steps: int = 20, warmup: int = 8, separate_calls: bool = Fa
     # clock ramp: after seconds of host-only work (the previous legs' CPU baselines, this leg's graph construction) the first few hundred
     # milliseconds of GPU work run at a fraction of the sustained clocks (measured: 7.5 instead of 2.8 ms per step over the first 150 ms);
     # untimed steps until 0.5 s of GPU activity have passed, like the headline's priming launches
+    plain = bool(os.environ.get("DYGNN_BENCH_TRAIN_PLAIN"))      # tools/prof_train.sh: exactly warmup + steps one-pass steps under the profiler
     t_prime = time.perf_counter()
-    while time.perf_counter() - t_prime < 0.5:
+    while not plain and time.perf_counter() - t_prime < 0.5:
         for i in range(warmup):
             step(i)
         torch.cuda.synchronize(dev)
@@ -647,7 +648,7 @@ def bench_train(dev, steps: int = 20, warmup: int = 8, separate_calls: bool = Fa
            "roofline": {"bound": "mfma", "achieved": round(flop / sec / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(flop / sec / (PEAK_F32_MFMA_TFLOPS * 1e12), 4), "traffic": None, "flop_per_step": flop,
                         "note": "3 x the forward's algorithmic flops over the whole step time (host work, optimizer and link predictor included)"}}
-    if not separate_calls:
+    if not separate_calls and not plain:
         # the reference's own call pattern (train_link_prediction.py:229-239: two calls per step) beside the one-pass form, same model state
         separate_calls = True
         for i in range(3):

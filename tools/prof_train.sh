@@ -3,6 +3,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$ROOT/gpurun_out/prof_tr"
+export DYGNN_BENCH_TRAIN_PLAIN=1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_tr" -o tr -- python3 "$ROOT/tools/bench_train.py" --steps 8 --warmup 2 --cpu-seconds 0 ${TRAIN_ARGS:-} > "$ROOT/gpurun_out/prof_tr.log" 2>&1
 python3 - "$ROOT/gpurun_out/prof_tr/tr_kernel_stats.csv" <<'PY'
 import csv, sys
