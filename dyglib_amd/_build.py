@@ -20,7 +20,7 @@ INCLUDE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 LIB_NAME = "libdygnn_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
 SOURCES = ["csr_host.cpp", "sampler.hip", "cooccurrence.hip", "dygformer_generic.hip", "dygformer_fused3.hip", "dygformer_train.hip",
-           "dygformer_api.hip", "tgat.hip", "metrics.hip"]
+           "dygformer_api.hip", "tgat.hip", "tgat_chain.hip", "metrics.hip"]
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-ffp-contract=off"]   # contractions are written explicitly (fmaf) where the oracle has them
@@ -71,16 +71,33 @@ def _digest() -> str:
     return h.hexdigest()
 
 
+def _src_digest(src: str, extra=()) -> str:
+    """One source + every header + the flags: an object is reused while none of them changed."""
+    h = hashlib.sha256()
+    for root in (CSRC, INCLUDE):
+        for fn in sorted(os.listdir(root)):
+            if fn.endswith(".h") or (root == CSRC and fn == src):
+                with open(os.path.join(root, fn), "rb") as f:
+                    h.update(fn.encode()), h.update(f.read())
+    h.update(" ".join([*CXXFLAGS, *extra]).encode())
+    return h.hexdigest()
+
+
 def _compile(src: str, obj_dir: str, extra=()) -> str:
     obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+    tag, dig = obj + ".digest", _src_digest(src, extra)
+    if os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == dig:
+        return obj
     cmd = [_hipcc(), *CXXFLAGS, *extra, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
     if src.endswith(".cpp"):
         cmd.insert(1, "-x"), cmd.insert(2, "hip")
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-    if r.stderr.strip():
+    if r.stderr.strip() and os.environ.get("DYGNN_BUILD_WARNINGS"):
         sys.stderr.write(r.stderr)
+    with open(tag, "w") as f:
+        f.write(dig)
     return obj
 
 
