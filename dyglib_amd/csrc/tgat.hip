@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "gemm.h"
+#include "tgat_chain.h"
 
 namespace dygnn {
 
@@ -38,22 +39,56 @@ __device__ __forceinline__ int64_t wave_lower_bound3(const double* __restrict__ 
 // level expansion: for the n nodes of a level (ids/times), sample the k most recent neighbours (utils/utils.py:200-209)
 // and append them to the next-lower level: lower = [this level ; neighbours (row-major n x k)].
 // nbr ids / edge ids int32, times float64 holding float32-rounded values (models/TGAT.py:107-110).
+// TGN (MemoryModel.py:108-109, :609): the level-0 set of a call is what it reads.  The FIRST wave to touch a node (atomic flag) either lists
+// it for the GRU update (pending message) or writes its feat0 row = memory + raw features directly.
+struct TgnTouch {
+    int32_t* flags;                // [N] zeroed before the launch, and right behind them the list length
+    int32_t* count;
+    int32_t* list;
+    const int32_t* has_msg;
+    const float *M, *raw;
+    float* feat0;
+    int64_t N;
+    int Fn;
+};
+__device__ __forceinline__ void tgn_touch(const TgnTouch& tt, int32_t id, int lane) {
+    const bool first = id >= 0 && id < tt.N && atomicExch(&tt.flags[id], 1) == 0;
+    const bool pend = first && tt.has_msg[id] != 0;
+    const uint64_t pm = __ballot(pend);
+    if (pm) {                                            // one atomic per wave reserves the list slots of its pending nodes
+        int32_t base = 0;
+        if (lane == __ffsll((long long)pm) - 1) base = atomicAdd(tt.count, __popcll(pm));
+        base = __shfl(base, __ffsll((long long)pm) - 1, 64);
+        if (pend) tt.list[base + __popcll(pm & ((1ull << lane) - 1))] = id;
+    }
+    uint64_t fm = __ballot(first && !pend);
+    while (fm) {
+        const int b = __ffsll((long long)fm) - 1;
+        fm &= fm - 1;
+        const int64_t node = __shfl(id, b, 64);
+        for (int f = lane; f < tt.Fn; f += kWave) tt.feat0[node * tt.Fn + f] = tt.M[node * tt.Fn + f] + tt.raw[node * tt.Fn + f];
+    }
+}
+// `src` given: this is the top level [src ; dst] read straight from the caller's int64 / float64 arrays (B pairs)
 __global__ __launch_bounds__(256) void k_tgat_expand(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cnbr,
                                                        const int32_t* __restrict__ ceid, const double* __restrict__ cts, int64_t num_nodes,
                                                        const int32_t* __restrict__ ids, const double* __restrict__ times, int64_t n, int k,
                                                        int32_t* __restrict__ lower_ids, double* __restrict__ lower_times,
-                                                       int32_t* __restrict__ nbr_eid, float* __restrict__ nbr_dt, const int32_t* __restrict__ n_live) {
+                                                       int32_t* __restrict__ nbr_eid, float* __restrict__ nbr_dt, const int32_t* __restrict__ n_live,
+                                                       const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const double* __restrict__ tq,
+                                                       int64_t B, const TgnTouch tt) {
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (q >= n || (n_live && q >= *n_live)) return;      // n = layout size of the level, *n_live = entries in use (de-duplicated level)
-    int64_t node = ids[q];
+    int64_t node = src ? (q < B ? src[q] : dst[q - B]) : (int64_t)ids[q];
     if (node < 0 || node >= num_nodes) node = 0;
-    const double t = times[q];
+    const double t = src ? tq[q < B ? q : q - B] : times[q];
     const int64_t lo = indptr[node], hi = indptr[node + 1];
     const int64_t i = wave_lower_bound3(cts, lo, hi, t, lane);
     const int64_t len = i - lo;
     const int m = (int)(len < k ? len : k), pad = k - m;
     if (lane == 0) { lower_ids[q] = (int32_t)node; lower_times[q] = t; }
+    int32_t mynb = -1;
     for (int j = lane; j < k; j += kWave) {
         int32_t nb = 0, e = 0;
         float tn = 0.f;
@@ -65,6 +100,11 @@ __global__ __launch_bounds__(256) void k_tgat_expand(const int64_t* __restrict__
         lower_times[n + q * k + j] = (double)tn;                        // hop-(l+1) queries use the float32 time
         nbr_eid[q * k + j] = e;
         nbr_dt[q * k + j] = (float)(t - (double)tn);                    // models/TGAT.py:116-119: f64 - f32 -> f64 -> .float()
+        mynb = nb;
+    }
+    if (tt.flags) {                                      // whole wave (k <= 64: a lane holds at most one neighbour), then the entry's own node
+        tgn_touch(tt, mynb, lane);
+        tgn_touch(tt, lane == 0 ? (int32_t)node : -1, lane);
     }
 }
 
@@ -522,14 +562,6 @@ __global__ void k_dedup_map(const int32_t* __restrict__ canon, const int32_t* __
     if (i < n) map[i] = cidx[canon[i]];
 }
 
-__global__ void k_cast_ids(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const double* __restrict__ t, int64_t B,
-                           int32_t* __restrict__ ids, double* __restrict__ times) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * B) return;
-    ids[i] = (int32_t)(i < B ? src[i] : dst[i - B]);
-    times[i] = t[i < B ? i : i - B];
-}
-
 __global__ void k_split_out(const float* __restrict__ h, int64_t B, int Fn, float* __restrict__ out_src, float* __restrict__ out_dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * B * Fn) return;
@@ -630,7 +662,8 @@ static bool tgat_dedup_active(const TgatPlan& p, bool presampled) {
 static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_csr* csr, const float* node_feat,
                              const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
                              float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream,
-                             const dygnn_tgat_levels* levels = nullptr, bool levels_in_workspace = false, bool expand_only = false) {
+                             const dygnn_tgat_levels* levels = nullptr, bool levels_in_workspace = false, bool expand_only = false,
+                             const TgnTouch* touch = nullptr) {
     if (int rc = check_tgat(cfg)) return rc;
     DYGNN_REQUIRE(w && w->time_w && w->time_b, "tgat: null weights");
     DYGNN_REQUIRE(levels || (csr && csr->indptr && csr->num_nodes >= 1), "tgat: bad csr");
@@ -669,15 +702,14 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
             }
         }
     } else {
-    // level L = [src ; dst]
-    hipLaunchKernelGGL(k_cast_ids, dim3((unsigned)ceil_div(2 * batch, 256)), dim3(256), 0, s, src, dst, times, batch, I32(p.ids[p.L]), F64(p.times[p.L]));
-    DYGNN_LAUNCH_CHECK();
-    // top-down: sample neighbours of every level, building the level below
+    // top-down: sample neighbours of every level, building the level below; level L = [src ; dst] is read from the caller's arrays
     for (int l = p.L; l >= 1; --l) {
         const bool dd = dedup && l == 1;          // level 1 is expanded from its distinct entries only
+        const bool top = l == p.L;
         hipLaunchKernelGGL(k_tgat_expand, dim3((unsigned)ceil_div(p.n[l], 4)), dim3(256), 0, s, csr->indptr, csr->nbr, csr->eid, csr->ts, csr->num_nodes,
                            dd ? I32(p.dd_ids) : I32(p.ids[l]), dd ? F64(p.dd_times) : F64(p.times[l]), p.n[l], p.k, I32(p.ids[l - 1]), F64(p.times[l - 1]),
-                           I32(p.eid[l]), F32(p.dt[l]), dd ? I32(p.dd_count) : (const int32_t*)nullptr);
+                           I32(p.eid[l]), F32(p.dt[l]), dd ? I32(p.dd_count) : (const int32_t*)nullptr, top ? src : nullptr, top ? dst : nullptr,
+                           top ? times : nullptr, batch, (touch && l == 1) ? *touch : TgnTouch{});
         DYGNN_LAUNCH_CHECK();
         if (dedup && l == 2) {                    // level 1 is complete: find its distinct (node, time) entries
             const int64_t n1 = p.n[1];
@@ -697,12 +729,24 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
     if (expand_only) return DYGNN_OK;
     // bottom-up: layer l turns level-(l-1) embeddings (raw features for l = 1) into level-l embeddings
     const float scale = (float)pow((double)p.hd, -0.5);
+    // The row-block chains need a block's rows in LDS (a property of the feature dims, never of the batch: rows keep the same bits at
+    // every batch size); DYGNN_TGAT_CHAIN=0 runs the product-by-product path through the general GEMM (A/B switch, read per call).
+    const char* ch_env = getenv("DYGNN_TGAT_CHAIN");
+    const bool chain = !(ch_env && ch_env[0] == '0') && chain::fits(p.Fn, p.Ft, p.Dkv, p.H);
     for (int l = 1; l <= p.L; ++l) {
         const dygnn_tgat_layer_weights& Lw = w->layers[l - 1];
         const int64_t n = p.n[l];
         const float* h_lower = l >= 2 ? F32(p.h[l - 1]) : nullptr;
         const int32_t* nl = dedup && l == 1 ? I32(p.dd_count) : nullptr;       // layer 1 runs over the distinct level-1 entries (count on the device)
         const int32_t* lmap = dedup && l == 2 ? I32(p.dd_map) : nullptr;       // layer 2 finds an entry's layer-1 row through the map
+        // the top level is [src rows ; dst rows]: when the caller's two outputs are one [2B, Fn] block it is written in place
+        const bool direct = l == p.L && out_dst == out_src + (size_t)batch * p.Fn;
+        float* h_out = direct ? out_src : F32(p.h[l]);
+        if (chain) {
+            // q_in -> q -> W_k^T q inside one workgroup per 16 / 32 rows (tgat_chain.hip): intermediates stay in LDS
+            chain::PreArgs pa{h_lower, node_feat, I32(p.ids[l - 1]), lmap, nl, w->time_w, w->time_b, Lw.query_w, Lw.key_w, F32(p.qk), n, p.Fn, p.Ft, p.Dkv, p.H};
+            if (int rc = chain::launch_pre(s, pa)) return rc;
+        } else {
         hipLaunchKernelGGL(k_tgat_inputs, dim3((unsigned)n), dim3(256), 0, s, h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]),
                            F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, (float*)nullptr, F32(p.q_in), nl, lmap);     // query rows
         DYGNN_LAUNCH_CHECK();
@@ -710,6 +754,7 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
         // qk[i][h] = W_k,h^T q_ih : per head [n][hd] x [hd][Dkv] (rows h*hd .. of key_w), one batched launch over the heads
         if (int rc = train::mm(s, F32(p.q), p.Dq, false, Lw.key_w, p.Dkv, false, F32(p.qk), p.H * p.Dkv, (int)n, p.Dkv, p.hd, nullptr, 1.f, 0.f, p.H, p.H, 0, p.hd,
                                0, (int64_t)p.hd * p.Dkv, 0, p.Dkv, false, false, nullptr, nl)) return rc;
+        }
         const dim3 grid((unsigned)ceil_div(n, 4));
         const size_t lds = (size_t)4 * p.H * p.k * sizeof(float);
         if (p.k <= 20 && p.H <= 2 && p.Dkv <= 512) {
@@ -724,6 +769,14 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
             hipLaunchKernelGGL((k_tgat_attn_lin<0>), grid, dim3(256), lds, s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]), F32(p.dt[l]),
                                w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z));
         DYGNN_LAUNCH_CHECK();
+        if (chain) {
+            // W_v z -> residual_fc + q_in -> LayerNorm -> MergeLayer, one workgroup per 16 / 32 rows
+            chain::PostArgs po{F32(p.z), h_lower, node_feat, I32(p.ids[l - 1]), lmap, nl, w->time_w, w->time_b, Lw.value_w, Lw.res_w, Lw.res_b, Lw.ln_w, Lw.ln_b,
+                               Lw.fc1_w, Lw.fc1_b, Lw.fc2_w, Lw.fc2_b, h_out, n, p.Fn, p.Ft, p.Dkv, p.H};
+            if (int rc = chain::launch_post(s, po)) return rc;
+            if (direct) return DYGNN_OK;
+            continue;
+        }
         // att[i][h*hd ..] = W_v,h z_ih : per head [n][Dkv] x [Dkv][hd]
         if (int rc = train::mm(s, F32(p.z), p.H * p.Dkv, false, Lw.value_w, p.Dkv, true, F32(p.att), p.Dq, (int)n, p.hd, p.Dkv, nullptr, 1.f, 0.f, p.H, p.H, 0, p.Dkv,
                                0, (int64_t)p.hd * p.Dkv, 0, p.hd, false, false, nullptr, nl)) return rc;
@@ -732,9 +785,7 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
                            n, p.Dq, p.Fn, F32(p.merge_in), nl);
         DYGNN_LAUNCH_CHECK();
         if (int rc = gemm_nt<true>(F32(p.merge_in), Lw.fc1_w, Lw.fc1_b, F32(p.hid), n, p.Fn, p.Dq + p.Fn, p.Fn, s, nl)) return rc;
-        // the top level is [src rows ; dst rows]: when the caller's two outputs are one [2B, Fn] block it is written in place
-        const bool direct = l == p.L && out_dst == out_src + (size_t)batch * p.Fn;
-        if (int rc = gemm_nt<false>(F32(p.hid), Lw.fc2_w, Lw.fc2_b, direct ? out_src : F32(p.h[l]), n, p.Fn, p.Fn, p.Fn, s, nl)) return rc;
+        if (int rc = gemm_nt<false>(F32(p.hid), Lw.fc2_w, Lw.fc2_b, h_out, n, p.Fn, p.Fn, p.Fn, s, nl)) return rc;
         if (direct) return DYGNN_OK;
     }
     hipLaunchKernelGGL(k_split_out, dim3((unsigned)ceil_div(2 * batch * p.Fn, 256)), dim3(256), 0, s, F32(p.h[p.L]), batch, p.Fn, out_src, out_dst);
@@ -767,18 +818,12 @@ __global__ void k_tgn_persist_clear(const int64_t* __restrict__ src, const int64
     if (threadIdx.x == 0) has_msg[node] = 0;
 }
 // Messages are stored source role first, then destination role (MemoryModel.py:147-161), and only a node's LAST stored message is ever
-// read (:284-291): entry e = role * B + i (role 0 = source), the winner of a node is its largest e
-__global__ void k_tgn_winner(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t B, int32_t* __restrict__ win, int64_t N) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 2 * B) return;
-    const int64_t node = e < B ? src[e] : dst[e - B];
-    if (node >= 0 && node < N) atomicMax(&win[node], (int32_t)e);
-}
+// read (:284-291): entry e = role * B + i (role 0 = source), the winner of a node is its largest e (k_tgn_message finds it by a scan)
 // new raw message of the role-node of entry e: [M[who] | M[other] | cos(w (t - U[who]) + b) | edge feature]  (MemoryModel.py:223-241)
 __global__ __launch_bounds__(256) void k_tgn_message(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const double* __restrict__ times,
                                                        const int64_t* __restrict__ eids, int64_t B, const float* __restrict__ M, const float* __restrict__ U,
                                                        const float* __restrict__ edge_feat, const float* __restrict__ tw, const float* __restrict__ tb,
-                                                       int Fn, int Fe, int Ft, const int32_t* __restrict__ win, float* __restrict__ msg,
+                                                       int Fn, int Fe, int Ft, float* __restrict__ msg,
                                                        double* __restrict__ msg_t, int32_t* __restrict__ has_msg, int64_t N) {
     const int64_t e = blockIdx.x;
     const bool role = e >= B;
@@ -786,7 +831,14 @@ __global__ __launch_bounds__(256) void k_tgn_message(const int64_t* __restrict__
     const int64_t node = role ? dst[i] : src[i];
     const int64_t o = role ? src[i] : dst[i];
     if (node < 0 || node >= N || o < 0 || o >= N) return;      // never index the state tables out of range
-    if (win[node] != (int32_t)e) return;           // only the last stored message is observable
+    // only the LAST stored message of a node is observable: entry e writes unless a later entry (with ids inside the tables) is the same node
+    int later = 0;
+    for (int64_t e2 = e + 1 + threadIdx.x; e2 < 2 * B; e2 += blockDim.x) {
+        const int64_t i2 = e2 >= B ? e2 - B : e2;
+        const int64_t n2 = e2 >= B ? dst[i2] : src[i2], o2 = e2 >= B ? src[i2] : dst[i2];
+        later |= (n2 == node && o2 >= 0 && o2 < N) ? 1 : 0;
+    }
+    if (__syncthreads_or(later)) return;
     const int D = 2 * Fn + Ft + Fe;
     const float dt = (float)times[i] - U[node];    // float32 - float32 (MemoryModel.py:232-233)
     float* m = msg + node * D;
@@ -800,81 +852,23 @@ __global__ __launch_bounds__(256) void k_tgn_message(const int64_t* __restrict__
     }
     if (threadIdx.x == 0) { msg_t[node] = times[i]; has_msg[node] = 1; }
 }
-__global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
 // ---- the nodes a call reads (TGN) --------------------------------------------------------------------------------------------
 // The reference updates the memory of every node with a pending message on every call (get_updated_memories over range(num_nodes),
 // MemoryModel.py:108-109) although a call only reads the rows of its level-0 set (roots and sampled neighbours).  Here the GRU runs
-// over exactly those: level-0 ids are marked in `flags`, marked nodes WITH a pending message are listed (their message / memory rows
-// are gathered, two GEMMs over the list, gates scattered back), marked nodes WITHOUT one get feat0 = memory + raw directly.  Rows
-// of a product do not depend on which other rows are in it, so every row read later is bit-identical to the all-nodes update.
-__global__ void k_mark_level0(const int32_t* __restrict__ ids0, int64_t n, int k, const int32_t* __restrict__ n_live, int64_t num_nodes,
-                              int32_t* __restrict__ flags) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (entry q, slot j): j = 0 the entry itself, 1..k its neighbours
-    const int64_t q = t / (k + 1);
-    const int j = (int)(t % (k + 1));
-    if (q >= n || (n_live && q >= *n_live)) return;
-    const int32_t id = j == 0 ? ids0[q] : ids0[n + q * k + (j - 1)];
-    if (id >= 0 && id < num_nodes) flags[id] = 1;
-}
-__global__ __launch_bounds__(256) void k_tgn_needed(const int32_t* __restrict__ flags, const int32_t* __restrict__ has_msg, const float* __restrict__ M,
-                                                     const float* __restrict__ raw, int64_t N, int Fn, int32_t* __restrict__ count,
-                                                     int32_t* __restrict__ list, float* __restrict__ feat0) {
-    const int lane = threadIdx.x & 63;
-    const int64_t node = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (node >= N || !flags[node]) return;
-    if (has_msg[node]) {
-        if (lane == 0) list[atomicAdd(count, 1)] = (int32_t)node;
-    } else {
-        for (int f = lane; f < Fn; f += kWave) feat0[node * Fn + f] = M[node * Fn + f] + raw[node * Fn + f];      // memory + raw (MemoryModel.py:609)
-    }
-}
-__global__ __launch_bounds__(256) void k_tgn_gather(const int32_t* __restrict__ list, const int32_t* __restrict__ count, const float* __restrict__ msg,
-                                                     const float* __restrict__ M, int Dm, int Fn, float* __restrict__ amsg, float* __restrict__ amem) {
-    const int64_t r = blockIdx.x;
-    if (r >= *count) return;
-    const int64_t node = list[r];
-    for (int f = threadIdx.x; f < Dm; f += blockDim.x) amsg[r * Dm + f] = msg[node * Dm + f];
-    for (int f = threadIdx.x; f < Fn; f += blockDim.x) amem[r * Fn + f] = M[node * Fn + f];
-}
-__global__ void k_tgn_gates_list(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ M, const float* __restrict__ raw,
-                                 const int32_t* __restrict__ list, const int32_t* __restrict__ count, int Fn, float* __restrict__ Mnew,
-                                 float* __restrict__ feat0) {
-    // nn.GRUCell, as k_tgn_gates, for the listed nodes (row r of gi / gh belongs to node list[r])
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t r = i / Fn;
-    const int f = (int)(i % Fn);
-    if (r >= *count) return;
-    const int64_t node = list[r];
-    const float h = M[node * Fn + f];
-    const float* a = gi + r * 3 * Fn;
-    const float* b = gh + r * 3 * Fn;
-    const float rr = 1.0f / (1.0f + expf(-(a[f] + b[f])));
-    const float z = 1.0f / (1.0f + expf(-(a[Fn + f] + b[Fn + f])));
-    const float nn = tanhf(a[2 * Fn + f] + rr * b[2 * Fn + f]);
-    const float hn = (1.0f - z) * nn + z * h;
-    Mnew[node * Fn + f] = hn;
-    feat0[node * Fn + f] = hn + raw[node * Fn + f];
-}
-
-struct TgnPlan { size_t gi, gh, Mnew, feat0, win, tgat, flags, list, count, amsg, amem, total; };
+// over exactly those: the level expansion flags every level-0 id it writes (tgn_touch in k_tgat_expand); the first wave to touch a node
+// lists it when it has a pending message (the GRU row-block kernel, tgat_chain.hip, gathers the listed rows, runs both gate products
+// and scatters the new memory and feat0 = memory + raw) or writes its feat0 row directly when it has none.  Rows of a product do not
+// depend on which other rows are in it, so every row read later is bit-identical to the all-nodes update.
+struct TgnPlan { size_t Mnew, feat0, tgat, flags, list, count, total; };
 static TgnPlan make_tgn_plan(const dygnn_tgat_config& c, int64_t N, int64_t B) {
     TgnPlan p{};
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~size_t(255); return r; };
-    p.gi = take((size_t)N * 3 * c.node_feat_dim * sizeof(float));
-    p.gh = take((size_t)N * 3 * c.node_feat_dim * sizeof(float));
     p.Mnew = take((size_t)N * c.node_feat_dim * sizeof(float));
     p.feat0 = take((size_t)N * c.node_feat_dim * sizeof(float));
-    p.win = take((size_t)N * sizeof(int32_t));
     p.flags = take((size_t)(N + 1) * sizeof(int32_t));       // [N] flags, then the list length (one memset clears both)
     p.count = p.flags + (size_t)N * sizeof(int32_t);
     p.list = take((size_t)N * sizeof(int32_t));
-    p.amsg = take((size_t)N * (2 * c.node_feat_dim + c.time_feat_dim + c.edge_feat_dim) * sizeof(float));
-    p.amem = take((size_t)N * c.node_feat_dim * sizeof(float));
     p.tgat = take(make_tgat_plan(c, B).total);
     p.total = o;
     return p;
@@ -935,50 +929,32 @@ static int tgn_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weigh
     if (workspace_bytes < p.total) { set_error("tgn: workspace too small (%zu < %zu bytes)", workspace_bytes, p.total); return DYGNN_E_WORKSPACE; }
     hipStream_t s = as_stream(stream);
     char* ws = static_cast<char*>(workspace);
-    float* gi = reinterpret_cast<float*>(ws + p.gi);
-    float* gh = reinterpret_cast<float*>(ws + p.gh);
     float* Mnew = reinterpret_cast<float*>(ws + p.Mnew);
     float* feat0 = reinterpret_cast<float*>(ws + p.feat0);
-    int32_t* win = reinterpret_cast<int32_t*>(ws + p.win);
-    // 0. the levels of this call (they depend on the graph only): their level-0 set is what the call reads
-    char* wt = ws + p.tgat;
-    const size_t wt_bytes = p.total - p.tgat;
-    if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, wt, wt_bytes, stream, nullptr, false, true)) return rc;
-    const TgatPlan tp = make_tgat_plan(*cfg, batch);
-    const int32_t* live = tgat_dedup_active(tp, false) ? reinterpret_cast<const int32_t*>(wt + tp.dd_count) : nullptr;
     int32_t* flags = reinterpret_cast<int32_t*>(ws + p.flags);
     int32_t* list = reinterpret_cast<int32_t*>(ws + p.list);
     int32_t* count = reinterpret_cast<int32_t*>(ws + p.count);
-    float* amsg = reinterpret_cast<float*>(ws + p.amsg);
-    float* amem = reinterpret_cast<float*>(ws + p.amem);
+    // 0. the levels of this call (they depend on the graph only).  Their level-0 set is what the call reads: the expansion flags it, lists
+    //    the nodes with a pending message and writes feat0 = memory + raw (MemoryModel.py:609) for the others
+    char* wt = ws + p.tgat;
+    const size_t wt_bytes = p.total - p.tgat;
     DYGNN_HIP(hipMemsetAsync(flags, 0, (size_t)(N + 1) * sizeof(int32_t), s));      // flags and, right behind them, the list length
-    hipLaunchKernelGGL(k_mark_level0, dim3((unsigned)ceil_div(tp.n[1] * (tp.k + 1), 256)), dim3(256), 0, s, reinterpret_cast<const int32_t*>(wt + tp.ids[0]), tp.n[1],
-                       tp.k, live, N, flags);
-    DYGNN_LAUNCH_CHECK();
-    // 1. updated memories of the nodes this call reads that have a pending message (the reference updates all nodes, MemoryModel.py:108-109;
-    //    see k_mark_level0): list them, gather their rows, two GEMMs over the list (row count on the device), gates scattered back
-    hipLaunchKernelGGL(k_tgn_needed, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, s, flags, st->has_msg, st->memory, node_feat, N, Fn, count, list, feat0);
-    DYGNN_LAUNCH_CHECK();
+    const TgnTouch touch{flags, count, list, st->has_msg, st->memory, node_feat, feat0, N, Fn};
+    if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, wt, wt_bytes, stream, nullptr, false, true, &touch)) return rc;
+    const TgatPlan tp = make_tgat_plan(*cfg, batch);
+    // 1. updated memories of the listed nodes (the reference updates all nodes, MemoryModel.py:108-109): one launch, row count on the device
     const int64_t ub = N < tp.n[0] ? N : tp.n[0];              // the list cannot be longer than the level-0 set
-    hipLaunchKernelGGL(k_tgn_gather, dim3((unsigned)ub), dim3(256), 0, s, list, count, st->msg, st->memory, Dm, Fn, amsg, amem);
-    DYGNN_LAUNCH_CHECK();
-    if (int rc = gemm_nt<false>(amsg, gru->weight_ih, gru->bias_ih, gi, ub, 3 * Fn, Dm, 3 * Fn, s, count)) return rc;
-    if (int rc = gemm_nt<false>(amem, gru->weight_hh, gru->bias_hh, gh, ub, 3 * Fn, Fn, 3 * Fn, s, count)) return rc;
-    hipLaunchKernelGGL(k_tgn_gates_list, dim3((unsigned)ceil_div(ub * Fn, 256)), dim3(256), 0, s, gi, gh, st->memory, node_feat, list, count, Fn, Mnew, feat0);
-    DYGNN_LAUNCH_CHECK();
+    const chain::GruArgs ga{list, count, st->msg, st->memory, node_feat, gru->weight_ih, gru->weight_hh, gru->bias_ih, gru->bias_hh, Mnew, feat0, ub, Dm, Fn};
+    if (int rc = chain::launch_gru(s, ga)) return rc;
     // 2. temporal graph attention over (memory + raw) features (GraphAttentionEmbedding, MemoryModel.py:548-664) on the levels built above
     if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, wt, wt_bytes, stream, nullptr, true)) return rc;
     if (!edges_are_positive) return DYGNN_OK;
     // 3. persist + clear for the batch nodes (MemoryModel.py:142-145)
     hipLaunchKernelGGL(k_tgn_persist_clear, dim3((unsigned)(2 * n_pos)), dim3(64), 0, s, src, dst, n_pos, Mnew, st->msg_time, Fn, st->memory, st->last_update, st->has_msg, N);
     DYGNN_LAUNCH_CHECK();
-    // 4. new raw messages of both roles (one winner pass, one message pass)
-    hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, win, N, -1);
-    DYGNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_tgn_winner, dim3((unsigned)ceil_div(2 * n_pos, 256)), dim3(256), 0, s, src, dst, n_pos, win, N);
-    DYGNN_LAUNCH_CHECK();
+    // 4. new raw messages of both roles (the last stored message of a node wins: k_tgn_message)
     hipLaunchKernelGGL(k_tgn_message, dim3((unsigned)(2 * n_pos)), dim3(256), 0, s, src, dst, times, edge_ids, n_pos, st->memory, st->last_update, edge_feat,
-                       w->time_w, w->time_b, Fn, Fe, Ft, win, st->msg, st->msg_time, st->has_msg, N);
+                       w->time_w, w->time_b, Fn, Fe, Ft, st->msg, st->msg_time, st->has_msg, N);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }
