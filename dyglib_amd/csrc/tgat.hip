@@ -42,31 +42,30 @@ __device__ __forceinline__ int64_t wave_lower_bound3(const double* __restrict__ 
 // TGN (MemoryModel.py:108-109, :609): the level-0 set of a call is what it reads.  The FIRST wave to touch a node (atomic flag) either lists
 // it for the GRU update (pending message) or writes its feat0 row = memory + raw features directly.
 struct TgnTouch {
-    int32_t* flags;                // [N] zeroed before the launch, and right behind them the list length
-    int32_t* count;
-    int32_t* list;
+    int32_t* flags;                // [N] zeroed before the launch, and right behind them the two list lengths
+    int32_t *count, *list;         // nodes with a pending message (GRU rows)
+    int32_t *count2, *list2;       // the others (feat0 = memory + raw)
     const int32_t* has_msg;
-    const float *M, *raw;
-    float* feat0;
     int64_t N;
-    int Fn;
 };
 __device__ __forceinline__ void tgn_touch(const TgnTouch& tt, int32_t id, int lane) {
     const bool first = id >= 0 && id < tt.N && atomicExch(&tt.flags[id], 1) == 0;
     const bool pend = first && tt.has_msg[id] != 0;
-    const uint64_t pm = __ballot(pend);
-    if (pm) {                                            // one atomic per wave reserves the list slots of its pending nodes
+    const uint64_t below = (1ull << lane) - 1;
+    const uint64_t pm = __ballot(pend), qm = __ballot(first && !pend);
+    if (pm) {                                            // one atomic per wave reserves the list slots of its nodes
+        const int leader = __ffsll((long long)pm) - 1;
         int32_t base = 0;
-        if (lane == __ffsll((long long)pm) - 1) base = atomicAdd(tt.count, __popcll(pm));
-        base = __shfl(base, __ffsll((long long)pm) - 1, 64);
-        if (pend) tt.list[base + __popcll(pm & ((1ull << lane) - 1))] = id;
+        if (lane == leader) base = atomicAdd(tt.count, __popcll(pm));
+        base = __shfl(base, leader, 64);
+        if (pend) tt.list[base + __popcll(pm & below)] = id;
     }
-    uint64_t fm = __ballot(first && !pend);
-    while (fm) {
-        const int b = __ffsll((long long)fm) - 1;
-        fm &= fm - 1;
-        const int64_t node = __shfl(id, b, 64);
-        for (int f = lane; f < tt.Fn; f += kWave) tt.feat0[node * tt.Fn + f] = tt.M[node * tt.Fn + f] + tt.raw[node * tt.Fn + f];
+    if (qm) {
+        const int leader = __ffsll((long long)qm) - 1;
+        int32_t base = 0;
+        if (lane == leader) base = atomicAdd(tt.count2, __popcll(qm));
+        base = __shfl(base, leader, 64);
+        if (first && !pend) tt.list2[base + __popcll(qm & below)] = id;
     }
 }
 // `src` given: this is the top level [src ; dst] read straight from the caller's int64 / float64 arrays (B pairs)
@@ -102,9 +101,9 @@ __global__ __launch_bounds__(256) void k_tgat_expand(const int64_t* __restrict__
         nbr_dt[q * k + j] = (float)(t - (double)tn);                    // models/TGAT.py:116-119: f64 - f32 -> f64 -> .float()
         mynb = nb;
     }
-    if (tt.flags) {                                      // whole wave (k <= 64: a lane holds at most one neighbour), then the entry's own node
-        tgn_touch(tt, mynb, lane);
-        tgn_touch(tt, lane == 0 ? (int32_t)node : -1, lane);
+    if (tt.flags) {                                      // whole wave (k <= 64: a lane holds at most one neighbour); the entry's own node rides on lane k
+        if (k < kWave) tgn_touch(tt, lane == k ? (int32_t)node : mynb, lane);
+        else { tgn_touch(tt, mynb, lane); tgn_touch(tt, lane == 0 ? (int32_t)node : -1, lane); }
     }
 }
 
@@ -574,7 +573,7 @@ struct TgatPlan {
     int64_t n[DYGNN_MAX_LAYERS + 1];       // level sizes: n[L] = 2B, n[l-1] = n[l] * (1 + k)
     // byte offsets
     size_t ids[DYGNN_MAX_LAYERS + 1], times[DYGNN_MAX_LAYERS + 1], eid[DYGNN_MAX_LAYERS + 1], dt[DYGNN_MAX_LAYERS + 1], h[DYGNN_MAX_LAYERS + 1];
-    size_t q_in, q, att, fc, merge_in, hid, qk, z, total;
+    size_t q_in, q, att, fc, merge_in, hid, qk, z, pack, total;
     // de-duplication of level L-1 (two-layer models, recent sampling): hash slots, representative / compact index / map per entry, compact level
     size_t dd_slots, dd_canon, dd_cidx, dd_map, dd_count, dd_ids, dd_times;
     uint32_t dd_cap;
@@ -615,6 +614,8 @@ static TgatPlan make_tgat_plan(const dygnn_tgat_config& c, int64_t B) {
         p.dd_ids = take((size_t)p.n[1] * sizeof(int32_t));
         p.dd_times = take((size_t)p.n[1] * sizeof(double));
     }
+    // packed weight fragments of the row-block chains (tgat_chain.h), with room for the GRU of a TGN call
+    p.pack = take(chain::pack_bytes(chain::plan_pack(p.L, p.Fn, p.Ft, p.Dkv, p.H > 0 ? p.H : 1, 2 * p.Fn + p.Ft + p.Fe)));
     p.total = o;
     return p;
 }
@@ -663,7 +664,7 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
                              const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
                              float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream,
                              const dygnn_tgat_levels* levels = nullptr, bool levels_in_workspace = false, bool expand_only = false,
-                             const TgnTouch* touch = nullptr) {
+                             const TgnTouch* touch = nullptr, bool packed = false) {
     if (int rc = check_tgat(cfg)) return rc;
     DYGNN_REQUIRE(w && w->time_w && w->time_b, "tgat: null weights");
     DYGNN_REQUIRE(levels || (csr && csr->indptr && csr->num_nodes >= 1), "tgat: bad csr");
@@ -733,6 +734,9 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
     // every batch size); DYGNN_TGAT_CHAIN=0 runs the product-by-product path through the general GEMM (A/B switch, read per call).
     const char* ch_env = getenv("DYGNN_TGAT_CHAIN");
     const bool chain = !(ch_env && ch_env[0] == '0') && chain::fits(p.Fn, p.Ft, p.Dkv, p.H);
+    const chain::PackPlan pp = chain::plan_pack(p.L, p.Fn, p.Ft, p.Dkv, p.H, 2 * p.Fn + p.Ft + p.Fe);
+    if (chain && !packed)
+        if (int rc = chain::pack(s, pp, p.L, p.Fn, p.Ft, p.Dkv, p.H, w, nullptr, 0, F32(p.pack))) return rc;
     for (int l = 1; l <= p.L; ++l) {
         const dygnn_tgat_layer_weights& Lw = w->layers[l - 1];
         const int64_t n = p.n[l];
@@ -744,7 +748,8 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
         float* h_out = direct ? out_src : F32(p.h[l]);
         if (chain) {
             // q_in -> q -> W_k^T q inside one workgroup per 16 / 32 rows (tgat_chain.hip): intermediates stay in LDS
-            chain::PreArgs pa{h_lower, node_feat, I32(p.ids[l - 1]), lmap, nl, w->time_w, w->time_b, Lw.query_w, Lw.key_w, F32(p.qk), n, p.Fn, p.Ft, p.Dkv, p.H};
+            chain::PreArgs pa{h_lower, node_feat, I32(p.ids[l - 1]), lmap, nl, w->time_w, w->time_b, F32(p.pack), pp.layer[l - 1].q, pp.layer[l - 1].k, F32(p.qk), n,
+                              p.Fn, p.Ft, p.Dkv, p.H};
             if (int rc = chain::launch_pre(s, pa)) return rc;
         } else {
         hipLaunchKernelGGL(k_tgat_inputs, dim3((unsigned)n), dim3(256), 0, s, h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]),
@@ -771,8 +776,9 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
         DYGNN_LAUNCH_CHECK();
         if (chain) {
             // W_v z -> residual_fc + q_in -> LayerNorm -> MergeLayer, one workgroup per 16 / 32 rows
-            chain::PostArgs po{F32(p.z), h_lower, node_feat, I32(p.ids[l - 1]), lmap, nl, w->time_w, w->time_b, Lw.value_w, Lw.res_w, Lw.res_b, Lw.ln_w, Lw.ln_b,
-                               Lw.fc1_w, Lw.fc1_b, Lw.fc2_w, Lw.fc2_b, h_out, n, p.Fn, p.Ft, p.Dkv, p.H};
+            const chain::LayerPack& y = pp.layer[l - 1];
+            chain::PostArgs po{F32(p.z), h_lower, node_feat, I32(p.ids[l - 1]), lmap, nl, w->time_w, w->time_b, F32(p.pack), y.v, y.r, y.f1, y.f2, Lw.res_b, Lw.ln_w,
+                               Lw.ln_b, Lw.fc1_b, Lw.fc2_b, h_out, n, p.Fn, p.Ft, p.Dkv, p.H};
             if (int rc = chain::launch_post(s, po)) return rc;
             if (direct) return DYGNN_OK;
             continue;
@@ -855,20 +861,22 @@ __global__ __launch_bounds__(256) void k_tgn_message(const int64_t* __restrict__
 // ---- the nodes a call reads (TGN) --------------------------------------------------------------------------------------------
 // The reference updates the memory of every node with a pending message on every call (get_updated_memories over range(num_nodes),
 // MemoryModel.py:108-109) although a call only reads the rows of its level-0 set (roots and sampled neighbours).  Here the GRU runs
-// over exactly those: the level expansion flags every level-0 id it writes (tgn_touch in k_tgat_expand); the first wave to touch a node
-// lists it when it has a pending message (the GRU row-block kernel, tgat_chain.hip, gathers the listed rows, runs both gate products
-// and scatters the new memory and feat0 = memory + raw) or writes its feat0 row directly when it has none.  Rows of a product do not
+// over exactly those: the level expansion flags every level-0 id it writes (tgn_touch in k_tgat_expand); the first lane to touch a node
+// lists it: with a pending message for the GRU row-block kernel (tgat_chain.hip: gathers the listed rows, runs both gate products and
+// scatters the new memory and feat0 = memory + raw), without one for the plain feat0 = memory + raw rows of the same launch.  Rows of a product do not
 // depend on which other rows are in it, so every row read later is bit-identical to the all-nodes update.
-struct TgnPlan { size_t Mnew, feat0, tgat, flags, list, count, total; };
+struct TgnPlan { size_t Mnew, feat0, tgat, flags, list, count, list2, count2, total; };
 static TgnPlan make_tgn_plan(const dygnn_tgat_config& c, int64_t N, int64_t B) {
     TgnPlan p{};
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~size_t(255); return r; };
     p.Mnew = take((size_t)N * c.node_feat_dim * sizeof(float));
     p.feat0 = take((size_t)N * c.node_feat_dim * sizeof(float));
-    p.flags = take((size_t)(N + 1) * sizeof(int32_t));       // [N] flags, then the list length (one memset clears both)
+    p.flags = take((size_t)(N + 2) * sizeof(int32_t));       // [N] flags, then the two list lengths (one memset clears all)
     p.count = p.flags + (size_t)N * sizeof(int32_t);
+    p.count2 = p.count + sizeof(int32_t);
     p.list = take((size_t)N * sizeof(int32_t));
+    p.list2 = take((size_t)N * sizeof(int32_t));
     p.tgat = take(make_tgat_plan(c, B).total);
     p.total = o;
     return p;
@@ -934,20 +942,28 @@ static int tgn_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weigh
     int32_t* flags = reinterpret_cast<int32_t*>(ws + p.flags);
     int32_t* list = reinterpret_cast<int32_t*>(ws + p.list);
     int32_t* count = reinterpret_cast<int32_t*>(ws + p.count);
-    // 0. the levels of this call (they depend on the graph only).  Their level-0 set is what the call reads: the expansion flags it, lists
-    //    the nodes with a pending message and writes feat0 = memory + raw (MemoryModel.py:609) for the others
+    int32_t* list2 = reinterpret_cast<int32_t*>(ws + p.list2);
+    int32_t* count2 = reinterpret_cast<int32_t*>(ws + p.count2);
+    // 0. the levels of this call (they depend on the graph only).  Their level-0 set is what the call reads: the expansion flags it and lists
+    //    the nodes with a pending message (GRU rows) and those without (feat0 = memory + raw, MemoryModel.py:609)
     char* wt = ws + p.tgat;
     const size_t wt_bytes = p.total - p.tgat;
-    DYGNN_HIP(hipMemsetAsync(flags, 0, (size_t)(N + 1) * sizeof(int32_t), s));      // flags and, right behind them, the list length
-    const TgnTouch touch{flags, count, list, st->has_msg, st->memory, node_feat, feat0, N, Fn};
+    DYGNN_HIP(hipMemsetAsync(flags, 0, (size_t)(N + 2) * sizeof(int32_t), s));      // flags and, right behind them, the list lengths
+    const TgnTouch touch{flags, count, list, count2, list2, st->has_msg, N};
     if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, wt, wt_bytes, stream, nullptr, false, true, &touch)) return rc;
     const TgatPlan tp = make_tgat_plan(*cfg, batch);
     // 1. updated memories of the listed nodes (the reference updates all nodes, MemoryModel.py:108-109): one launch, row count on the device
     const int64_t ub = N < tp.n[0] ? N : tp.n[0];              // the list cannot be longer than the level-0 set
-    const chain::GruArgs ga{list, count, st->msg, st->memory, node_feat, gru->weight_ih, gru->weight_hh, gru->bias_ih, gru->bias_hh, Mnew, feat0, ub, Dm, Fn};
+    //    (weights of the GRU and of the layers packed into operand fragments first: tgat_chain.h)
+    DYGNN_REQUIRE(chain::fits(tp.Fn, tp.Ft, tp.Dkv, tp.H), "tgn: feature dims do not fit the row-block kernels");
+    const chain::PackPlan pp = chain::plan_pack(tp.L, tp.Fn, tp.Ft, tp.Dkv, tp.H, Dm);
+    float* pk = reinterpret_cast<float*>(wt + tp.pack);
+    if (int rc = chain::pack(s, pp, tp.L, tp.Fn, tp.Ft, tp.Dkv, tp.H, w, gru, Dm, pk)) return rc;
+    const chain::GruArgs ga{list, count, list2, count2, st->msg, st->memory, node_feat, pk, pp.ih, pp.hh, gru->bias_ih, gru->bias_hh, Mnew, feat0, ub, Dm, Fn};
     if (int rc = chain::launch_gru(s, ga)) return rc;
     // 2. temporal graph attention over (memory + raw) features (GraphAttentionEmbedding, MemoryModel.py:548-664) on the levels built above
-    if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, wt, wt_bytes, stream, nullptr, true)) return rc;
+    if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, wt, wt_bytes, stream, nullptr, true, false, nullptr,
+                                   true)) return rc;
     if (!edges_are_positive) return DYGNN_OK;
     // 3. persist + clear for the batch nodes (MemoryModel.py:142-145)
     hipLaunchKernelGGL(k_tgn_persist_clear, dim3((unsigned)(2 * n_pos)), dim3(64), 0, s, src, dst, n_pos, Mnew, st->msg_time, Fn, st->memory, st->last_update, st->has_msg, N);

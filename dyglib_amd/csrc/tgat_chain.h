@@ -10,6 +10,20 @@ namespace chain {
 // whether a 16-row block of these dims fits the LDS (a property of the model's dims, never of the batch)
 bool fits(int Fn, int Ft, int Dkv, int H);
 
+// The weights are re-laid per call into MFMA-operand fragments (1 KiB = the float4 of each of the 64 lanes, zero-padded tiles) in the
+// order the waves consume them: a wave's weight load is then one contiguous KiB instead of 16 strided 64-byte pieces.  (The call
+// takes raw state_dict pointers and knows nothing about their history, so the 2 MB per layer are packed every call: one launch.)
+struct LayerPack { uint32_t q, k, v, r, f1, f2; };        // fragment offsets of the six products of a layer
+struct PackPlan {
+    LayerPack layer[DYGNN_MAX_LAYERS];
+    uint32_t ih, hh;                                       // GRU (TGN only)
+    uint32_t total;                                        // fragments
+};
+PackPlan plan_pack(int L, int Fn, int Ft, int Dkv, int H, int gru_Dm /* 0: no GRU */);
+inline size_t pack_bytes(const PackPlan& p) { return (size_t)p.total * 1024; }
+int pack(hipStream_t s, const PackPlan& p, int L, int Fn, int Ft, int Dkv, int H, const dygnn_tgat_weights* w, const dygnn_gru_weights* gru, int gru_Dm,
+         float* dst);
+
 // rows i < n (or < *n_live): q_in = [h(self) | cos(b)] -> q = W_q q_in -> qk[i][h][:] = W_k,h^T q_ih          (models/modules.py:150-170)
 struct PreArgs {
     const float* h_lower;          // layer >= 2: rows of the level below ([.][Fn]); NULL: layer 1 reads node_feat[lower_ids[i]]
@@ -18,7 +32,8 @@ struct PreArgs {
     const int32_t* lower_map;      // layer 2 over a de-duplicated level 1: entry -> row of h_lower (or NULL)
     const int32_t* n_live;         // device-side row count (or NULL: n)
     const float *tw, *tb;          // time encoder
-    const float *query_w, *key_w;  // [Dq][Dq], [Dq][Dkv]
+    const float* pk;               // packed weights
+    uint32_t off_q, off_k;
     float* qk;                     // [n][H][Dkv]
     int64_t n;
     int Fn, Ft, Dkv, H;
@@ -34,7 +49,9 @@ struct PostArgs {
     const int32_t* lower_map;
     const int32_t* n_live;
     const float *tw, *tb;
-    const float *value_w, *res_w, *res_b, *ln_w, *ln_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+    const float* pk;
+    uint32_t off_v, off_r, off_f1, off_f2;
+    const float *res_b, *ln_w, *ln_b, *fc1_b, *fc2_b;
     float* out;                    // [n][Fn]
     int64_t n;
     int Fn, Ft, Dkv, H;
@@ -42,11 +59,14 @@ struct PostArgs {
 int launch_post(hipStream_t s, const PostArgs& a);
 
 // TGN: nn.GRUCell over the listed nodes (row r = node list[r], r < *count <= max_rows): message and memory rows gathered, both gate
-// products, gates, Mnew[node] and feat0[node] = Mnew[node] + raw[node] scattered -- one launch (MemoryModel.py:462-500)
+// products, gates, Mnew[node] and feat0[node] = Mnew[node] + raw[node] scattered (MemoryModel.py:462-500); and, in the same launch,
+// feat0[node] = M[node] + raw[node] for the nodes of list2 (the call's nodes without a pending message)
 struct GruArgs {
-    const int32_t *list, *count;
+    const int32_t *list, *count, *list2, *count2;
     const float *msg, *M, *raw;
-    const float *w_ih, *w_hh, *b_ih, *b_hh;
+    const float* pk;
+    uint32_t off_ih, off_hh;
+    const float *b_ih, *b_hh;
     float *Mnew, *feat0;
     int64_t max_rows;
     int Dm, Fn;
