@@ -39,35 +39,14 @@ __device__ __forceinline__ int64_t wave_lower_bound3(const double* __restrict__ 
 // level expansion: for the n nodes of a level (ids/times), sample the k most recent neighbours (utils/utils.py:200-209)
 // and append them to the next-lower level: lower = [this level ; neighbours (row-major n x k)].
 // nbr ids / edge ids int32, times float64 holding float32-rounded values (models/TGAT.py:107-110).
-// TGN (MemoryModel.py:108-109, :609): the level-0 set of a call is what it reads.  The FIRST wave to touch a node (atomic flag) either lists
-// it for the GRU update (pending message) or writes its feat0 row = memory + raw features directly.
+// TGN (MemoryModel.py:108-109, :609): the level-0 set of a call is what it reads.  Every level-0 slot (entry q, position j) stores
+// owner[id] = slot -- plain stores, some slot of a node wins; chain::pack's list blocks (tgat_chain.h: ListArgs) let the winner list its
+// node.  (Flags claimed with returning atomics cost 25 us per step here: 8,800 device-scope atomics on a 28-KB array.)
 struct TgnTouch {
-    int32_t* flags;                // [N] zeroed before the launch, and right behind them the two list lengths
-    int32_t *count, *list;         // nodes with a pending message (GRU rows)
-    int32_t *count2, *list2;       // the others (feat0 = memory + raw)
-    const int32_t* has_msg;
+    int32_t* owner;                // [N]; entries of nodes outside this call's level-0 set are stale and never read
+    int32_t* counts;               // the two list lengths, zeroed here for the list pass of the next launch
     int64_t N;
 };
-__device__ __forceinline__ void tgn_touch(const TgnTouch& tt, int32_t id, int lane) {
-    const bool first = id >= 0 && id < tt.N && atomicExch(&tt.flags[id], 1) == 0;
-    const bool pend = first && tt.has_msg[id] != 0;
-    const uint64_t below = (1ull << lane) - 1;
-    const uint64_t pm = __ballot(pend), qm = __ballot(first && !pend);
-    if (pm) {                                            // one atomic per wave reserves the list slots of its nodes
-        const int leader = __ffsll((long long)pm) - 1;
-        int32_t base = 0;
-        if (lane == leader) base = atomicAdd(tt.count, __popcll(pm));
-        base = __shfl(base, leader, 64);
-        if (pend) tt.list[base + __popcll(pm & below)] = id;
-    }
-    if (qm) {
-        const int leader = __ffsll((long long)qm) - 1;
-        int32_t base = 0;
-        if (lane == leader) base = atomicAdd(tt.count2, __popcll(qm));
-        base = __shfl(base, leader, 64);
-        if (first && !pend) tt.list2[base + __popcll(qm & below)] = id;
-    }
-}
 // `src` given: this is the top level [src ; dst] read straight from the caller's int64 / float64 arrays (B pairs)
 __global__ __launch_bounds__(256) void k_tgat_expand(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cnbr,
                                                        const int32_t* __restrict__ ceid, const double* __restrict__ cts, int64_t num_nodes,
@@ -78,6 +57,7 @@ __global__ __launch_bounds__(256) void k_tgat_expand(const int64_t* __restrict__
                                                        int64_t B, const TgnTouch tt) {
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tt.owner && blockIdx.x == 0 && threadIdx.x < 2) tt.counts[threadIdx.x] = 0;
     if (q >= n || (n_live && q >= *n_live)) return;      // n = layout size of the level, *n_live = entries in use (de-duplicated level)
     int64_t node = src ? (q < B ? src[q] : dst[q - B]) : (int64_t)ids[q];
     if (node < 0 || node >= num_nodes) node = 0;
@@ -86,8 +66,10 @@ __global__ __launch_bounds__(256) void k_tgat_expand(const int64_t* __restrict__
     const int64_t i = wave_lower_bound3(cts, lo, hi, t, lane);
     const int64_t len = i - lo;
     const int m = (int)(len < k ? len : k), pad = k - m;
-    if (lane == 0) { lower_ids[q] = (int32_t)node; lower_times[q] = t; }
-    int32_t mynb = -1;
+    if (lane == 0) {
+        lower_ids[q] = (int32_t)node; lower_times[q] = t;
+        if (tt.owner && node < tt.N) tt.owner[node] = (int32_t)(q * (k + 1) + k);
+    }
     for (int j = lane; j < k; j += kWave) {
         int32_t nb = 0, e = 0;
         float tn = 0.f;
@@ -99,11 +81,7 @@ __global__ __launch_bounds__(256) void k_tgat_expand(const int64_t* __restrict__
         lower_times[n + q * k + j] = (double)tn;                        // hop-(l+1) queries use the float32 time
         nbr_eid[q * k + j] = e;
         nbr_dt[q * k + j] = (float)(t - (double)tn);                    // models/TGAT.py:116-119: f64 - f32 -> f64 -> .float()
-        mynb = nb;
-    }
-    if (tt.flags) {                                      // whole wave (k <= 64: a lane holds at most one neighbour); the entry's own node rides on lane k
-        if (k < kWave) tgn_touch(tt, lane == k ? (int32_t)node : mynb, lane);
-        else { tgn_touch(tt, mynb, lane); tgn_touch(tt, lane == 0 ? (int32_t)node : -1, lane); }
+        if (tt.owner && nb >= 0 && nb < tt.N) tt.owner[nb] = (int32_t)(q * (k + 1) + j);
     }
 }
 
@@ -707,10 +685,11 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
     for (int l = p.L; l >= 1; --l) {
         const bool dd = dedup && l == 1;          // level 1 is expanded from its distinct entries only
         const bool top = l == p.L;
+        const bool tch = touch && l == 1;
         hipLaunchKernelGGL(k_tgat_expand, dim3((unsigned)ceil_div(p.n[l], 4)), dim3(256), 0, s, csr->indptr, csr->nbr, csr->eid, csr->ts, csr->num_nodes,
                            dd ? I32(p.dd_ids) : I32(p.ids[l]), dd ? F64(p.dd_times) : F64(p.times[l]), p.n[l], p.k, I32(p.ids[l - 1]), F64(p.times[l - 1]),
                            I32(p.eid[l]), F32(p.dt[l]), dd ? I32(p.dd_count) : (const int32_t*)nullptr, top ? src : nullptr, top ? dst : nullptr,
-                           top ? times : nullptr, batch, (touch && l == 1) ? *touch : TgnTouch{});
+                           top ? times : nullptr, batch, tch ? *touch : TgnTouch{});
         DYGNN_LAUNCH_CHECK();
         if (dedup && l == 2) {                    // level 1 is complete: find its distinct (node, time) entries
             const int64_t n1 = p.n[1];
@@ -730,10 +709,12 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
     if (expand_only) return DYGNN_OK;
     // bottom-up: layer l turns level-(l-1) embeddings (raw features for l = 1) into level-l embeddings
     const float scale = (float)pow((double)p.hd, -0.5);
-    // The row-block chains need a block's rows in LDS (a property of the feature dims, never of the batch: rows keep the same bits at
-    // every batch size); DYGNN_TGAT_CHAIN=0 runs the product-by-product path through the general GEMM (A/B switch, read per call).
+    // Two forms of a layer.  Row-block chains (tgat_chain.hip; three launches, intermediates in LDS): every workgroup streams the layer's
+    // 2 MB of weights through its own CU, which pays when a level has few rows -- TGN calls (one step of a few hundred roots; they come
+    // with their weights packed).  Product by product through the general GEMM: TGAT's levels of 10^4..10^5 rows.  The choice depends on
+    // the caller, never on the batch, so a row keeps its bits at every batch size; DYGNN_TGAT_CHAIN=0/1 forces one (A/B switch, read per call).
     const char* ch_env = getenv("DYGNN_TGAT_CHAIN");
-    const bool chain = !(ch_env && ch_env[0] == '0') && chain::fits(p.Fn, p.Ft, p.Dkv, p.H);
+    const bool chain = (ch_env && (ch_env[0] == '0' || ch_env[0] == '1') ? ch_env[0] == '1' : packed) && chain::fits(p.Fn, p.Ft, p.Dkv, p.H);
     const chain::PackPlan pp = chain::plan_pack(p.L, p.Fn, p.Ft, p.Dkv, p.H, 2 * p.Fn + p.Ft + p.Fe);
     if (chain && !packed)
         if (int rc = chain::pack(s, pp, p.L, p.Fn, p.Ft, p.Dkv, p.H, w, nullptr, 0, F32(p.pack))) return rc;
@@ -807,37 +788,23 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
 // (MemoryModel.py:389-407) but its aggregator only ever reads the last element (:284-291), and lists are cleared
 // whole (:400-407), so the last message is the entire observable state.
 // ================================================================================================
-// persist the update for the batch nodes that have a pending message and clear it (MemoryModel.py:142-145, :425-459).  A node that
-// occurs several times is handled by several workgroups: each either still sees the flag and writes the same values, or sees it cleared
-__global__ void k_tgn_persist_clear(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t B, const float* __restrict__ Mnew,
-                                    const double* __restrict__ msg_t, int Fn, float* __restrict__ M, float* __restrict__ U, int32_t* __restrict__ has_msg,
-                                    int64_t N) {
-    const int64_t r = blockIdx.x;                  // 0..2B-1
-    const int64_t node = r < B ? src[r] : dst[r - B];
-    if (node < 0 || node >= N) return;             // ids outside the state tables are never written (the host API raises IndexError for them)
-    const bool pending = has_msg[node] != 0;       // the same for every thread of the workgroup unless a twin clears it meanwhile: harmless
-    if (pending) {
-        for (int f = threadIdx.x; f < Fn; f += blockDim.x) M[node * Fn + f] = Mnew[node * Fn + f];
-        if (threadIdx.x == 0) U[node] = (float)msg_t[node];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) has_msg[node] = 0;
-}
-// Messages are stored source role first, then destination role (MemoryModel.py:147-161), and only a node's LAST stored message is ever
-// read (:284-291): entry e = role * B + i (role 0 = source), the winner of a node is its largest e (k_tgn_message finds it by a scan)
-// new raw message of the role-node of entry e: [M[who] | M[other] | cos(w (t - U[who]) + b) | edge feature]  (MemoryModel.py:223-241)
-__global__ __launch_bounds__(256) void k_tgn_message(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const double* __restrict__ times,
-                                                       const int64_t* __restrict__ eids, int64_t B, const float* __restrict__ M, const float* __restrict__ U,
-                                                       const float* __restrict__ edge_feat, const float* __restrict__ tw, const float* __restrict__ tb,
-                                                       int Fn, int Fe, int Ft, float* __restrict__ msg,
-                                                       double* __restrict__ msg_t, int32_t* __restrict__ has_msg, int64_t N) {
+// End of a positive call, one launch: for every batch node (a) persist the updated memory if it had a pending message and (b) store its
+// new raw message (MemoryModel.py:142-161, :223-241, :425-459).  Messages are stored source role first, then destination role, and only a
+// node's LAST stored message is ever read (:284-291): entry e = role * B + i (role 0 = source); the last entry of a node does the work
+// for that node, the others exit.  "Had a pending message" is read from the call's pendf (written by the list pass), not from
+// has_msg, which this kernel rewrites; the other endpoint's updated memory is Mnew when it was pending, M when not (nobody writes it then),
+// so no workgroup reads what another one writes.
+__global__ __launch_bounds__(256) void k_tgn_commit(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const double* __restrict__ times,
+                                                      const int64_t* __restrict__ eids, int64_t B, const float* __restrict__ Mnew, const int32_t* __restrict__ pendf,
+                                                      float* __restrict__ M, float* __restrict__ U, const float* __restrict__ edge_feat,
+                                                      const float* __restrict__ tw, const float* __restrict__ tb, int Fn, int Fe, int Ft, float* __restrict__ msg,
+                                                      double* __restrict__ msg_t, int32_t* __restrict__ has_msg, int64_t N) {
     const int64_t e = blockIdx.x;
     const bool role = e >= B;
     const int64_t i = role ? e - B : e;
     const int64_t node = role ? dst[i] : src[i];
     const int64_t o = role ? src[i] : dst[i];
-    if (node < 0 || node >= N || o < 0 || o >= N) return;      // never index the state tables out of range
-    // only the LAST stored message of a node is observable: entry e writes unless a later entry (with ids inside the tables) is the same node
+    if (node < 0 || node >= N || o < 0 || o >= N) return;      // never index the state tables out of range (the host API raises IndexError for such ids)
     int later = 0;
     for (int64_t e2 = e + 1 + threadIdx.x; e2 < 2 * B; e2 += blockDim.x) {
         const int64_t i2 = e2 >= B ? e2 - B : e2;
@@ -845,35 +812,47 @@ __global__ __launch_bounds__(256) void k_tgn_message(const int64_t* __restrict__
         later |= (n2 == node && o2 >= 0 && o2 < N) ? 1 : 0;
     }
     if (__syncthreads_or(later)) return;
+    const bool pend = pendf[node] != 0, pend_o = pendf[o] != 0;
+    const float* mn = pend ? Mnew + node * Fn : M + node * Fn;      // the node's updated memory (MemoryModel.py:142-145 persists exactly this)
+    const float* mo = pend_o ? Mnew + o * Fn : M + o * Fn;
+    const float u = pend ? (float)msg_t[node] : U[node];            // last-update time after the persist (:447-459)
     const int D = 2 * Fn + Ft + Fe;
-    const float dt = (float)times[i] - U[node];    // float32 - float32 (MemoryModel.py:232-233)
+    const float dt = (float)times[i] - u;                           // float32 - float32 (MemoryModel.py:232-233)
     float* m = msg + node * D;
     for (int f = threadIdx.x; f < D; f += blockDim.x) {
         float v;
-        if (f < Fn) v = M[node * Fn + f];
-        else if (f < 2 * Fn) v = M[o * Fn + (f - Fn)];
+        if (f < Fn) v = mn[f];
+        else if (f < 2 * Fn) v = mo[f - Fn];
         else if (f < 2 * Fn + Ft) v = cosf(fmaf(dt, tw[f - 2 * Fn], tb[f - 2 * Fn]));
         else v = edge_feat[(size_t)eids[i] * Fe + (f - 2 * Fn - Ft)];
         m[f] = v;
+        if (pend && f < Fn) M[node * Fn + f] = v;                   // persist
     }
-    if (threadIdx.x == 0) { msg_t[node] = times[i]; has_msg[node] = 1; }
+    __syncthreads();                                                // msg_t[node] was read above by every thread
+    if (threadIdx.x == 0) {
+        if (pend) U[node] = u;
+        msg_t[node] = times[i];
+        has_msg[node] = 1;
+    }
 }
+
 // ---- the nodes a call reads (TGN) --------------------------------------------------------------------------------------------
 // The reference updates the memory of every node with a pending message on every call (get_updated_memories over range(num_nodes),
 // MemoryModel.py:108-109) although a call only reads the rows of its level-0 set (roots and sampled neighbours).  Here the GRU runs
-// over exactly those: the level expansion flags every level-0 id it writes (tgn_touch in k_tgat_expand); the first lane to touch a node
-// lists it: with a pending message for the GRU row-block kernel (tgat_chain.hip: gathers the listed rows, runs both gate products and
-// scatters the new memory and feat0 = memory + raw), without one for the plain feat0 = memory + raw rows of the same launch.  Rows of a product do not
-// depend on which other rows are in it, so every row read later is bit-identical to the all-nodes update.
-struct TgnPlan { size_t Mnew, feat0, tgat, flags, list, count, list2, count2, total; };
+// over exactly those: every level-0 slot names itself owner of its node (k_tgat_expand); the winning slot lists the node (the list blocks
+// of chain::pack's launch): with a pending message for the GRU row-block kernel (tgat_chain.hip: gathers the listed rows, runs both gate
+// products and scatters the new memory and feat0 = memory + raw), without one for the plain feat0 = memory + raw rows of the same launch.
+// Rows of a product do not depend on which other rows are in it, so every row read later is bit-identical to the all-nodes update.
+struct TgnPlan { size_t Mnew, feat0, tgat, owner, pendf, list, count, list2, count2, total; };
 static TgnPlan make_tgn_plan(const dygnn_tgat_config& c, int64_t N, int64_t B) {
     TgnPlan p{};
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~size_t(255); return r; };
     p.Mnew = take((size_t)N * c.node_feat_dim * sizeof(float));
     p.feat0 = take((size_t)N * c.node_feat_dim * sizeof(float));
-    p.flags = take((size_t)(N + 2) * sizeof(int32_t));       // [N] flags, then the two list lengths (one memset clears all)
-    p.count = p.flags + (size_t)N * sizeof(int32_t);
+    p.owner = take((size_t)N * sizeof(int32_t));             // the level-0 slot that speaks for a node / whether the node had a pending message
+    p.pendf = take((size_t)N * sizeof(int32_t));
+    p.count = take(2 * sizeof(int32_t));                     // the two list lengths
     p.count2 = p.count + sizeof(int32_t);
     p.list = take((size_t)N * sizeof(int32_t));
     p.list2 = take((size_t)N * sizeof(int32_t));
@@ -939,37 +918,37 @@ static int tgn_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weigh
     char* ws = static_cast<char*>(workspace);
     float* Mnew = reinterpret_cast<float*>(ws + p.Mnew);
     float* feat0 = reinterpret_cast<float*>(ws + p.feat0);
-    int32_t* flags = reinterpret_cast<int32_t*>(ws + p.flags);
+    int32_t* owner = reinterpret_cast<int32_t*>(ws + p.owner);
+    int32_t* pendf = reinterpret_cast<int32_t*>(ws + p.pendf);
     int32_t* list = reinterpret_cast<int32_t*>(ws + p.list);
     int32_t* count = reinterpret_cast<int32_t*>(ws + p.count);
     int32_t* list2 = reinterpret_cast<int32_t*>(ws + p.list2);
     int32_t* count2 = reinterpret_cast<int32_t*>(ws + p.count2);
-    // 0. the levels of this call (they depend on the graph only).  Their level-0 set is what the call reads: the expansion flags it and lists
-    //    the nodes with a pending message (GRU rows) and those without (feat0 = memory + raw, MemoryModel.py:609)
+    // 0. the levels of this call (they depend on the graph only).  Their level-0 set is what the call reads: every slot of it names itself
+    //    owner of its node (k_tgat_expand)
     char* wt = ws + p.tgat;
     const size_t wt_bytes = p.total - p.tgat;
-    DYGNN_HIP(hipMemsetAsync(flags, 0, (size_t)(N + 2) * sizeof(int32_t), s));      // flags and, right behind them, the list lengths
-    const TgnTouch touch{flags, count, list, count2, list2, st->has_msg, N};
+    const TgnTouch touch{owner, count, N};
     if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, wt, wt_bytes, stream, nullptr, false, true, &touch)) return rc;
     const TgatPlan tp = make_tgat_plan(*cfg, batch);
-    // 1. updated memories of the listed nodes (the reference updates all nodes, MemoryModel.py:108-109): one launch, row count on the device
-    const int64_t ub = N < tp.n[0] ? N : tp.n[0];              // the list cannot be longer than the level-0 set
-    //    (weights of the GRU and of the layers packed into operand fragments first: tgat_chain.h)
+    // 1. one launch: the owners list their nodes -- pending message: GRU rows; none: feat0 = memory + raw (MemoryModel.py:609) -- and the weights
+    //    of the GRU and of the layers are packed into operand fragments (tgat_chain.h); then the updated memories of the listed nodes (the
+    //    reference updates all nodes, MemoryModel.py:108-109): one launch, row count on the device
     DYGNN_REQUIRE(chain::fits(tp.Fn, tp.Ft, tp.Dkv, tp.H), "tgn: feature dims do not fit the row-block kernels");
     const chain::PackPlan pp = chain::plan_pack(tp.L, tp.Fn, tp.Ft, tp.Dkv, tp.H, Dm);
     float* pk = reinterpret_cast<float*>(wt + tp.pack);
-    if (int rc = chain::pack(s, pp, tp.L, tp.Fn, tp.Ft, tp.Dkv, tp.H, w, gru, Dm, pk)) return rc;
+    const int32_t* live = tgat_dedup_active(tp, false) ? reinterpret_cast<const int32_t*>(wt + tp.dd_count) : nullptr;
+    const chain::ListArgs la{reinterpret_cast<const int32_t*>(wt + tp.ids[0]), live, owner, st->has_msg, pendf, count, list, count2, list2, tp.n[1], N, tp.k};
+    if (int rc = chain::pack(s, pp, tp.L, tp.Fn, tp.Ft, tp.Dkv, tp.H, w, gru, Dm, pk, &la)) return rc;
+    const int64_t ub = N < tp.n[0] ? N : tp.n[0];              // the list cannot be longer than the level-0 set
     const chain::GruArgs ga{list, count, list2, count2, st->msg, st->memory, node_feat, pk, pp.ih, pp.hh, gru->bias_ih, gru->bias_hh, Mnew, feat0, ub, Dm, Fn};
     if (int rc = chain::launch_gru(s, ga)) return rc;
     // 2. temporal graph attention over (memory + raw) features (GraphAttentionEmbedding, MemoryModel.py:548-664) on the levels built above
     if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, wt, wt_bytes, stream, nullptr, true, false, nullptr,
                                    true)) return rc;
     if (!edges_are_positive) return DYGNN_OK;
-    // 3. persist + clear for the batch nodes (MemoryModel.py:142-145)
-    hipLaunchKernelGGL(k_tgn_persist_clear, dim3((unsigned)(2 * n_pos)), dim3(64), 0, s, src, dst, n_pos, Mnew, st->msg_time, Fn, st->memory, st->last_update, st->has_msg, N);
-    DYGNN_LAUNCH_CHECK();
-    // 4. new raw messages of both roles (the last stored message of a node wins: k_tgn_message)
-    hipLaunchKernelGGL(k_tgn_message, dim3((unsigned)(2 * n_pos)), dim3(256), 0, s, src, dst, times, edge_ids, n_pos, st->memory, st->last_update, edge_feat,
+    // 3. persist the updated memories of the batch nodes and store their new raw messages (MemoryModel.py:142-161)
+    hipLaunchKernelGGL(k_tgn_commit, dim3((unsigned)(2 * n_pos)), dim3(256), 0, s, src, dst, times, edge_ids, n_pos, Mnew, pendf, st->memory, st->last_update, edge_feat,
                        w->time_w, w->time_b, Fn, Fe, Ft, st->msg, st->msg_time, st->has_msg, N);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;

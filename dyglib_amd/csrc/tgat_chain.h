@@ -21,8 +21,20 @@ struct PackPlan {
 };
 PackPlan plan_pack(int L, int Fn, int Ft, int Dkv, int H, int gru_Dm /* 0: no GRU */);
 inline size_t pack_bytes(const PackPlan& p) { return (size_t)p.total * 1024; }
+// TGN: the lists of a call's level-0 nodes, built in the same launch as the packing (independent work, one launch less).  Every level-0
+// slot s = (entry q, position j: 0..k-1 a neighbour, k the entry itself) has written owner[id] = s (plain stores: one of a node's slots
+// wins); the winning slot lists its node: list (pending message: GRU rows) or list2 (none: feat0 = memory + raw) and records which in
+// pendf[id].  Slots count inside their workgroup, one global atomic per workgroup and list.
+struct ListArgs {
+    const int32_t* ids0;           // level-0 ids: [n entries | n*k neighbours]
+    const int32_t* n_live;         // device-side entry count (or NULL: n)
+    const int32_t *owner, *has_msg;
+    int32_t *pendf, *count, *list, *count2, *list2;
+    int64_t n, N;
+    int k;
+};
 int pack(hipStream_t s, const PackPlan& p, int L, int Fn, int Ft, int Dkv, int H, const dygnn_tgat_weights* w, const dygnn_gru_weights* gru, int gru_Dm,
-         float* dst);
+         float* dst, const ListArgs* lists = nullptr);
 
 // rows i < n (or < *n_live): q_in = [h(self) | cos(b)] -> q = W_q q_in -> qk[i][h][:] = W_k,h^T q_ih          (models/modules.py:150-170)
 struct PreArgs {

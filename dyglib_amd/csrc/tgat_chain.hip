@@ -1,40 +1,39 @@
 // Row-block chains of the TGAT / TGN layer (see tgat_chain.h).  gfx950 only.
 //
-// One workgroup (8 wave64) owns R = 16*MT rows of a level.  Every product of the chain is Out[R][N] = Act[R][K] . W^T with the
-// activations in LDS and the weight operand streamed from the packed buffer (L2-resident: a layer is 2 MB) straight into the MFMA A
-// operand, `v_mfma_f32_16x16x4_f32`, transposed form: accumulator tile = Out^T[n = 4g+r][m = c] for lane (c = lane&15, g = lane>>4), so
-// a lane ends with four consecutive n of row c = one float4 store into the next product's LDS operand.
-//  * "kc" products (nn.Linear weights [N][K], contraction along a weight row): fragment (tile, chunk) holds for lane (c,g) the float4
-//    W[16 tile + c][16 chunk + 4g ..]; the lane reads Act[c][16 chunk + 4g ..] from LDS: 4 MFMAs per fragment, 16 k per step;
-//  * "km" products (W_k,h^T q: contraction along weight ROWS): fragment (tile, step) holds W[4 step + g][64 tile + 4c ..]; the lane reads the
-//    scalar Act[c][4 step + g]; its four elements feed four accumulators whose tiles interleave to 64 consecutive n.
-// Why packed: read in place, a wave's float4 load of a [16 rows][16 k] operand is 16 strided 64-byte pieces; the vector L1 looks every
-// quarter-wave's 16 lines up separately and the first version of these kernels ran at 270 ns per step whatever the prefetch depth
-// (profiles/r02_tgn_chain_notes.md).  A packed fragment is one contiguous KiB.
-// LDS row strides are 4 (mod 8) floats: the 16 rows of a b128 read (and the 16 x 4 words of the b32 read) fall on distinct banks; rows
-// are zero-padded to the 16-k chunk so no step needs a mask.
-// A row's result depends on that row's data only (an MFMA column never mixes with another), in the same order for either MT, so rows
-// are bit-identical whatever batch or block they sit in.
+// One workgroup (8 wave64) owns R = 4*MT rows of a level (R = 4 .. 32, chosen from the level size so that small levels still spread over
+// the chip).  Every product of the chain is Out[R][N] = Act[R][K] . W^T with the activations in LDS and the weight operand streamed from
+// the packed buffer (L2-resident: a layer is 2 MB) straight into the MFMA A operand of `v_mfma_f32_4x4x1_16b_f32`: sixteen independent
+// 4x4 outer products per instruction, used as 4 groups of n (4 outputs each) x 4 slices of k against FOUR rows -- full matrix-core rate
+// at four rows per workgroup, where a 16x16x4 tile would need sixteen (the first version of these kernels used 16-row tiles: a TGN
+// step's 800 roots were 50 workgroups on 256 CUs, each bound by its own CU's matrix pipe and L1; profiles/r02_tgn_chain_notes.md).
+//  * fragment (tile, chunk) = 16 outputs n x 16 k = 1 KiB: lane L = 16 ng + 4 ks + i holds the float4 W[16 tile + 4 ng + i][16 chunk + 4 ks ..];
+//    instruction t of a step multiplies element t with Act[4m + j][16 chunk + 4 ks + t] (lane's j = L & 3; one b128 LDS read per 4 rows);
+//  * accumulator of lane (ng, ks, j): partial sums over k-slice ks of Out[4m + j][16 tile + 4 ng + 0..3]; at the end of a tile the four
+//    slices are added in a fixed order (two cross-lane adds) and the ks = 0 lanes hold a float4 of four consecutive n of one row.
+// So a row's value is the same sequence of operations for every MT: rows are bit-identical whatever batch or block they sit in.
+// Both weight layouts ([N][K] of nn.Linear, and key_w used as W_k,h^T: contraction along weight ROWS) are packed into this one
+// fragment form (k_pack), zero-padded to whole tiles / chunks so no step needs a mask; LDS rows are zero-padded to the 16-k chunk.
+#include <cstdlib>
 #include "tgat_chain.h"
 
 namespace dygnn {
 namespace chain {
 
 using f4 = __attribute__((ext_vector_type(4))) float;
-__device__ __forceinline__ f4 cmfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
 __host__ __device__ inline int r16(int K) { return (K + 15) & ~15; }
-__host__ __device__ inline int pad_ld(int K) {           // smallest row stride >= K with stride % 8 == 4
-    const int l = (K + 3) & ~3;
-    return (l & 4) ? l : l + 4;
+__host__ __device__ inline int pad_ld(int K) {           // smallest row stride >= K with stride % 32 == 16: the four rows of an operand read fall on distinct banks
+    const int l = r16(K);
+    return (l & 16) ? l : l + 16;
 }
 
 // ---- packing ----------------------------------------------------------------------------------------------------------------------
 struct PackDesc {
     const float* src;
-    int ld, N, K, type;            // type 0: kc (tile = 16 rows n, step = 16 k) ; 1: km (tile = 64 columns n, step = 4 rows k)
+    int ld, N, K, type;            // type 0: src[n][k] (nn.Linear) ; 1: src[k][n] (used transposed); tile = 16 n, step = 16 k either way
     int tph;                       // tiles per head (per-head products: tile t belongs to head t / tph, matrix src + head * hstride)
     int64_t hstride;
     uint32_t off, ntiles, nsteps;
@@ -42,10 +41,43 @@ struct PackDesc {
 constexpr int kMaxDesc = 6 * DYGNN_MAX_LAYERS + 2;
 struct PackTable { PackDesc d[kMaxDesc]; int n; uint32_t total; };
 
-__global__ __launch_bounds__(256) void k_pack(const PackTable tb, f4* __restrict__ dst) {
-    const uint32_t frag = blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void k_pack(const PackTable tb, f4* __restrict__ dst, const ListArgs la, unsigned list_blocks) {
+    if (blockIdx.x < list_blocks) {       // ---- the call's node lists (TGN), see ListArgs
+        __shared__ int32_t s_cnt[2], s_base[2];
+        if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        const int lane = threadIdx.x & 63;
+        const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        const int64_t q = slot / (la.k + 1);
+        const int jj = (int)(slot - q * (la.k + 1));
+        const int64_t nl = la.n_live ? (int64_t)*la.n_live : la.n;
+        int32_t id = -1;
+        if (q < la.n && q < nl) id = jj == la.k ? la.ids0[q] : la.ids0[la.n + q * la.k + jj];
+        const bool first = id >= 0 && id < la.N && la.owner[id] == (int32_t)slot;
+        const bool pend = first && la.has_msg[id] != 0;
+        if (first) la.pendf[id] = pend ? 1 : 0;
+        const uint64_t below = (1ull << lane) - 1;
+        const uint64_t pm = __ballot(pend), qm = __ballot(first && !pend);
+        int32_t o1 = 0, o2 = 0;
+        if (lane == 0) {
+            if (pm) o1 = atomicAdd(&s_cnt[0], __popcll(pm));
+            if (qm) o2 = atomicAdd(&s_cnt[1], __popcll(qm));
+        }
+        o1 = __shfl(o1, 0, 64);
+        o2 = __shfl(o2, 0, 64);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_base[0] = s_cnt[0] ? atomicAdd(la.count, s_cnt[0]) : 0;
+            s_base[1] = s_cnt[1] ? atomicAdd(la.count2, s_cnt[1]) : 0;
+        }
+        __syncthreads();
+        if (pend) la.list[s_base[0] + o1 + __popcll(pm & below)] = id;
+        if (first && !pend) la.list2[s_base[1] + o2 + __popcll(qm & below)] = id;
+        return;
+    }
+    const uint32_t frag = (blockIdx.x - list_blocks) * 4 + (threadIdx.x >> 6);
     if (frag >= tb.total) return;
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63;
     int di = 0;
     for (int i = 1; i < tb.n; ++i)
         if (frag >= tb.d[i].off) di = i;
@@ -54,18 +86,20 @@ __global__ __launch_bounds__(256) void k_pack(const PackTable tb, f4* __restrict
     const int h = (int)t / d.tph, lt = (int)t - h * d.tph;
     const float* m = d.src + (int64_t)h * d.hstride;
     f4 v = f4{0.f, 0.f, 0.f, 0.f};
-    if (d.type == 0) {
-        const int n = 16 * lt + c, k = 16 * (int)st + 4 * g;
-        if (n < d.N && k < d.K) v = *reinterpret_cast<const f4*>(m + (size_t)n * d.ld + k);
-    } else {
-        const int k = 4 * (int)st + g, n = 64 * lt + 4 * c;
-        if (k < d.K && n < d.N) v = *reinterpret_cast<const f4*>(m + (size_t)k * d.ld + n);
+    const int n = 16 * lt + 4 * (lane >> 4) + (lane & 3), k = 16 * (int)st + 4 * ((lane >> 2) & 3);
+    if (n < d.N && k < d.K) {
+        if (d.type == 0) v = *reinterpret_cast<const f4*>(m + (size_t)n * d.ld + k);               // W[n][k ..]       (K % 4 == 0)
+        else {                                                                                       // W[k ..][n]: the contraction runs along weight rows
+            v.x = m[(size_t)k * d.ld + n];
+            if (k + 1 < d.K) v.y = m[(size_t)(k + 1) * d.ld + n];
+            if (k + 2 < d.K) v.z = m[(size_t)(k + 2) * d.ld + n];
+            if (k + 3 < d.K) v.w = m[(size_t)(k + 3) * d.ld + n];
+        }
     }
     dst[(size_t)frag * 64 + lane] = v;
 }
 
 static uint32_t kc_frags(int N, int K, int heads = 1) { return (uint32_t)heads * ((N + 15) / 16) * ((K + 15) / 16); }
-static uint32_t km_frags(int N, int K, int heads = 1) { return (uint32_t)heads * ((N + 63) / 64) * ((K + 3) / 4); }
 
 PackPlan plan_pack(int L, int Fn, int Ft, int Dkv, int H, int gru_Dm) {
     PackPlan p{};
@@ -73,23 +107,23 @@ PackPlan plan_pack(int L, int Fn, int Ft, int Dkv, int H, int gru_Dm) {
     uint32_t o = 0;
     for (int l = 0; l < L; ++l) {
         LayerPack& y = p.layer[l];
-        y.q = o; o += kc_frags(Dq, Dq);
-        y.k = o; o += km_frags(Dkv, hd, H);
+        y.q = o; o += kc_frags(hd, Dq, H);
+        y.k = o; o += kc_frags(Dkv, hd, H);
         y.v = o; o += kc_frags(hd, Dkv, H);
         y.r = o; o += kc_frags(Dq, Dq);
         y.f1 = o; o += kc_frags(Fn, Dq + Fn);
         y.f2 = o; o += kc_frags(Fn, Fn);
     }
     if (gru_Dm > 0) {
-        p.ih = o; o += kc_frags(3 * Fn, gru_Dm);
-        p.hh = o; o += kc_frags(3 * Fn, Fn);
+        p.ih = o; o += kc_frags(Fn, gru_Dm, 3);      // per gate: a slice of memory dims takes the same tiles of every gate
+        p.hh = o; o += kc_frags(Fn, Fn, 3);
     }
     p.total = o;
     return p;
 }
 
 int pack(hipStream_t s, const PackPlan& p, int L, int Fn, int Ft, int Dkv, int H, const dygnn_tgat_weights* w, const dygnn_gru_weights* gru, int gru_Dm,
-         float* dst) {
+         float* dst, const ListArgs* lists) {
     PackTable tb{};
     const int Dq = Fn + Ft, hd = Dq / H;
     auto kc = [&](const float* src, int ld, int N, int K, uint32_t off, int heads = 1, int64_t hstride = 0) {
@@ -99,142 +133,89 @@ int pack(hipStream_t s, const PackPlan& p, int L, int Fn, int Ft, int Dkv, int H
     for (int l = 0; l < L; ++l) {
         const dygnn_tgat_layer_weights& Lw = w->layers[l];
         const LayerPack& y = p.layer[l];
-        kc(Lw.query_w, Dq, Dq, Dq, y.q);
-        tb.d[tb.n++] = PackDesc{Lw.key_w, Dkv, Dkv, hd, 1, (Dkv + 63) / 64, (int64_t)hd * Dkv, y.k, (uint32_t)(H * ((Dkv + 63) / 64)), (uint32_t)((hd + 3) / 4)};
+        kc(Lw.query_w, Dq, hd, Dq, y.q, H, (int64_t)hd * Dq);
+        tb.d[tb.n++] = PackDesc{Lw.key_w, Dkv, Dkv, hd, 1, (Dkv + 15) / 16, (int64_t)hd * Dkv, y.k, (uint32_t)(H * ((Dkv + 15) / 16)), (uint32_t)((hd + 15) / 16)};
         kc(Lw.value_w, Dkv, hd, Dkv, y.v, H, (int64_t)hd * Dkv);
         kc(Lw.res_w, Dq, Dq, Dq, y.r);
         kc(Lw.fc1_w, Dq + Fn, Fn, Dq + Fn, y.f1);
         kc(Lw.fc2_w, Fn, Fn, Fn, y.f2);
     }
     if (gru_Dm > 0) {
-        kc(gru->weight_ih, gru_Dm, 3 * Fn, gru_Dm, p.ih);
-        kc(gru->weight_hh, Fn, 3 * Fn, Fn, p.hh);
+        kc(gru->weight_ih, gru_Dm, Fn, gru_Dm, p.ih, 3, (int64_t)Fn * gru_Dm);
+        kc(gru->weight_hh, Fn, Fn, Fn, p.hh, 3, (int64_t)Fn * Fn);
     }
-    tb.total = p.total;
-    hipLaunchKernelGGL(k_pack, dim3((p.total + 3) / 4), dim3(256), 0, s, tb, reinterpret_cast<f4*>(dst));
+    tb.total = gru_Dm > 0 ? p.total : p.ih ? p.ih : p.total;      // (a TGAT call leaves the GRU part of the plan alone)
+    const unsigned lb = lists ? (unsigned)ceil_div(lists->n * (lists->k + 1), 256) : 0;
+    hipLaunchKernelGGL(k_pack, dim3(lb + (tb.total + 3) / 4), dim3(256), 0, s, tb, reinterpret_cast<f4*>(dst), lists ? *lists : ListArgs{}, lb);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }
 
 // ---- the weight stream of a wave ------------------------------------------------------------------------------------------------
-// A stage gives wave w the tiles t = w, w + 8, ... < T.  Their fragments form ONE sequence of steps (tile by tile, k-step by k-step) that
+// A stage gives wave w the tiles t = w, w + 8, ... < T.  Their fragments form ONE sequence of steps (tile by tile, chunk by chunk) that
 // runs through a ring of U float4 registers filled U steps ahead -- across tile boundaries, so the stream only drains at the end of a
 // stage.  Steady state is branch-free but for the tile epilogue (refills are always issued; beyond the stream they re-read the wave's
-// first tile), so the compiler counts the loads in flight (s_waitcnt vmcnt(U-1)) instead of draining them.  The LDS operand of step
-// s+1 is read before the MFMAs of step s; a step's MFMAs go to two (kc) / four (km) independent accumulators.
-// AF: act(t) = LDS base of the activation operand of tile t.  Ep(t, acc): the finished tile.
+// first tile), so the compiler counts the loads in flight (s_waitcnt vmcnt(U-1)) instead of draining them.  The LDS operands of step
+// s+1 are read before the MFMAs of step s.
+// AF: act(t) = LDS base of the activation operand of tile t.  Ep(t, acc): the finished tile -- every lane holds the sums of
+// Out[4m + j][16t + 4ng .. +3] in acc[m]; the ks == 0 lanes store.
 constexpr int U = 8;
 
-template <int MT, class AF, class Ep>
-__device__ __forceinline__ void stream_kc(const f4* __restrict__ pk, int T, int nch, int wave, int lane, int lda, AF actf, Ep ep) {
+struct IdTile { __device__ __forceinline__ int operator()(int t) const { return t; } };
+// TM: local tile index -> tile index in the packed stage (a workgroup that owns a slice of a stage's tiles)
+template <int MT, class AF, class Ep, class TM = IdTile>
+__device__ __forceinline__ void stream4(const f4* __restrict__ pk, int T, int nch, int wave, int lane, int lda, AF actf, Ep ep, TM tmap = TM()) {
     if (wave >= T) return;
-    const int c = lane & 15, g = lane >> 4;
+    const int j = lane & 3, ks = (lane >> 2) & 3;
     const int S = ((T - wave + kWaves - 1) / kWaves) * nch;
     const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
     int pt = wave, pch = 0;                                           // prefetch cursor
-    const f4* pp = pk + (size_t)wave * nch * 64 + lane;
+    const f4* pp = pk + (size_t)tmap(wave) * nch * 64 + lane;
     f4 ring[U];
     auto fetch = [&](f4& dst) {
         dst = *pp;
         pp += 64;
-        if (++pch == nch) { pch = 0; pt += kWaves; pp = pk + (size_t)(pt < T ? pt : wave) * nch * 64 + lane; }
+        if (++pch == nch) { pch = 0; pt += kWaves; pp = pk + (size_t)tmap(pt < T ? pt : wave) * nch * 64 + lane; }
     };
 #pragma unroll
     for (int u = 0; u < U; ++u) fetch(ring[u]);
     int ct = wave, cch = 0;                                           // consume cursor
-    const float* ab = actf(ct) + c * lda + 4 * g;
-    f4 acc0[MT], acc1[MT], bn[MT];
+    const float* ab = actf(ct) + j * lda + 4 * ks;
+    f4 acc[MT], bn[MT];
 #pragma unroll
-    for (int j = 0; j < MT; ++j) { acc0[j] = zero; acc1[j] = zero; bn[j] = *reinterpret_cast<const f4*>(ab + j * 16 * lda); }
+    for (int m = 0; m < MT; ++m) { acc[m] = zero; bn[m] = *reinterpret_cast<const f4*>(ab + m * 4 * lda); }
     auto step = [&](f4& slot, bool refill) {
         const f4 w = slot;
         f4 b[MT];
 #pragma unroll
-        for (int j = 0; j < MT; ++j) b[j] = bn[j];
+        for (int m = 0; m < MT; ++m) b[m] = bn[m];
         const bool tile_end = cch + 1 == nch;
         const int nt = tile_end ? ct + kWaves : ct, nc = tile_end ? 0 : cch + 1;
-        const float* nab = tile_end ? actf(nt < T ? nt : ct) + c * lda + 4 * g : ab;
+        const float* nab = tile_end ? actf(nt < T ? nt : ct) + j * lda + 4 * ks : ab;
 #pragma unroll
-        for (int j = 0; j < MT; ++j) bn[j] = *reinterpret_cast<const f4*>(nab + j * 16 * lda + 16 * nc);      // (behind the last step: a valid, unused read)
+        for (int m = 0; m < MT; ++m) bn[m] = *reinterpret_cast<const f4*>(nab + m * 4 * lda + 16 * nc);      // (behind the last step: a valid, unused read)
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            acc0[j] = cmfma(w.x, b[j].x, acc0[j]);
-            acc1[j] = cmfma(w.y, b[j].y, acc1[j]);
-            acc0[j] = cmfma(w.z, b[j].z, acc0[j]);
-            acc1[j] = cmfma(w.w, b[j].w, acc1[j]);
-        }
+        for (int m = 0; m < MT; ++m) acc[m] = mfma4(w.x, b[m].x, acc[m]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = mfma4(w.y, b[m].y, acc[m]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = mfma4(w.z, b[m].z, acc[m]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = mfma4(w.w, b[m].w, acc[m]);
         if (refill) fetch(slot);
         if (tile_end) {
             f4 r[MT];
 #pragma unroll
-            for (int j = 0; j < MT; ++j) { r[j] = acc0[j] + acc1[j]; acc0[j] = zero; acc1[j] = zero; }
+            for (int m = 0; m < MT; ++m) {          // k-slices 0 + 1, 2 + 3, then the pairs: fixed order
+                f4 v = acc[m];
+                v.x += __shfl_xor(v.x, 4, 64); v.y += __shfl_xor(v.y, 4, 64); v.z += __shfl_xor(v.z, 4, 64); v.w += __shfl_xor(v.w, 4, 64);
+                v.x += __shfl_xor(v.x, 8, 64); v.y += __shfl_xor(v.y, 8, 64); v.z += __shfl_xor(v.z, 8, 64); v.w += __shfl_xor(v.w, 8, 64);
+                r[m] = v;
+                acc[m] = zero;
+            }
             ep(ct, r);
         }
         ct = nt; cch = nc; ab = nab;
-    };
-    int s0 = 0;
-    for (; s0 + U <= S; s0 += U) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) step(ring[u], true);
-    }
-#pragma unroll
-    for (int u = 0; u < U - 1; ++u)
-        if (s0 + u < S) step(ring[u], false);
-}
-
-// acc[tt][j][r] = Out[16j + c][64 t' + 16g + 4r + tt] (t' = the tile's block of n)
-template <int MT, class AF, class Ep>
-__device__ __forceinline__ void stream_km(const f4* __restrict__ pk, int T, int nst, int wave, int lane, int lda, AF actf, Ep ep) {
-    if (wave >= T) return;
-    const int c = lane & 15, g = lane >> 4;
-    const int S = ((T - wave + kWaves - 1) / kWaves) * nst;
-    const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
-    int pt = wave, pst = 0;
-    const f4* pp = pk + (size_t)wave * nst * 64 + lane;
-    f4 ring[U];
-    auto fetch = [&](f4& dst) {
-        dst = *pp;
-        pp += 64;
-        if (++pst == nst) { pst = 0; pt += kWaves; pp = pk + (size_t)(pt < T ? pt : wave) * nst * 64 + lane; }
-    };
-#pragma unroll
-    for (int u = 0; u < U; ++u) fetch(ring[u]);
-    int ct = wave, cst = 0;
-    const float* ab = actf(ct) + c * lda + g;
-    f4 acc[4][MT];
-    float bn[MT];
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        bn[j] = ab[j * 16 * lda];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) acc[tt][j] = zero;
-    }
-    auto step = [&](f4& slot, bool refill) {
-        const f4 w = slot;
-        float b[MT];
-#pragma unroll
-        for (int j = 0; j < MT; ++j) b[j] = bn[j];
-        const bool tile_end = cst + 1 == nst;
-        const int nt = tile_end ? ct + kWaves : ct, ns = tile_end ? 0 : cst + 1;
-        const float* nab = tile_end ? actf(nt < T ? nt : ct) + c * lda + g : ab;
-#pragma unroll
-        for (int j = 0; j < MT; ++j) bn[j] = nab[j * 16 * lda + 4 * ns];
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            acc[0][j] = cmfma(w.x, b[j], acc[0][j]);
-            acc[1][j] = cmfma(w.y, b[j], acc[1][j]);
-            acc[2][j] = cmfma(w.z, b[j], acc[2][j]);
-            acc[3][j] = cmfma(w.w, b[j], acc[3][j]);
-        }
-        if (refill) fetch(slot);
-        if (tile_end) {
-            ep(ct, acc);
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int j = 0; j < MT; ++j) acc[tt][j] = zero;
-        }
-        ct = nt; cst = ns; ab = nab;
     };
     int s0 = 0;
     for (; s0 + U <= S; s0 += U) {
@@ -252,13 +233,15 @@ template <int MT>
 __device__ __forceinline__ void fill_qin(float* qin, int ldq, const float* __restrict__ tw, const float* __restrict__ tb, const float* __restrict__ h_lower,
                                          const float* __restrict__ node_feat, const int32_t* __restrict__ lower_ids, const int32_t* __restrict__ lower_map,
                                          int64_t i0, int64_t nl, int Fn, int Dq, int wave, int lane) {
-    constexpr int RW = 2 * MT;
+    constexpr int R = 4 * MT, RW = (R + kWaves - 1) / kWaves;
     const float* hsrc[RW];
-    bool valid[RW];
+    bool valid[RW], have[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-        const int64_t i = i0 + wave + kWaves * r;
-        valid[r] = i < nl;
+        const int rr = wave + kWaves * r;
+        const int64_t i = i0 + rr;
+        have[r] = rr < R;
+        valid[r] = have[r] && i < nl;
         int64_t idx = 0;
         if (valid[r]) idx = h_lower ? (lower_map ? (int64_t)lower_map[i] : i) : (int64_t)lower_ids[i];
         hsrc[r] = (h_lower ? h_lower : node_feat) + idx * Fn;
@@ -269,71 +252,73 @@ __device__ __forceinline__ void fill_qin(float* qin, int ldq, const float* __res
 #pragma unroll
             for (int r = 0; r < RW; ++r) v[r] = hsrc[r][f];
 #pragma unroll
-            for (int r = 0; r < RW; ++r) qin[(wave + kWaves * r) * ldq + f] = valid[r] ? v[r] : 0.f;
+            for (int r = 0; r < RW; ++r)
+                if (have[r]) qin[(wave + kWaves * r) * ldq + f] = valid[r] ? v[r] : 0.f;
         } else {
             const float v = f < Dq ? cosf(fmaf(0.0f, tw[f - Fn], tb[f - Fn])) : 0.f;      // the query's time feature: dt = 0 (models/TGAT.py:84)
 #pragma unroll
-            for (int r = 0; r < RW; ++r) qin[(wave + kWaves * r) * ldq + f] = valid[r] ? v : 0.f;
+            for (int r = 0; r < RW; ++r)
+                if (have[r]) qin[(wave + kWaves * r) * ldq + f] = valid[r] ? v : 0.f;
         }
     }
 }
 
+// grid = (row blocks, heads): a workgroup computes ONE head's q_h = W_q,h q_in and qk_h = W_k,h^T q_h (the heads share nothing but q_in,
+// which each re-reads), so a row block's weight stream is split over H CUs
 template <int MT>
 __global__ __launch_bounds__(kThreads) void k_tgat_pre(const PreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 15, g = lane >> 4;
-    constexpr int R = 16 * MT;
+    const int j = lane & 3, ks = (lane >> 2) & 3, ng = lane >> 4;
+    constexpr int R = 4 * MT;
     const int64_t i0 = (int64_t)blockIdx.x * R;
+    const int h = blockIdx.y;
     const int64_t nl = a.n_live ? (int64_t)*a.n_live : a.n;
     if (i0 >= nl) return;
     const int Fn = a.Fn, Ft = a.Ft, Dq = Fn + Ft, Dkv = a.Dkv, H = a.H, hd = Dq / H;
-    const int ldq = pad_ld(r16(Dq));
+    const int ldq = pad_ld(Dq), ldh = pad_ld(hd);
     float* qin = lds;
-    float* q = qin + R * ldq;
+    float* q = qin + R * ldq;                 // [R][ldh]: this head's q, zero beyond hd (zero-packed weight rows)
     const f4* pk = reinterpret_cast<const f4*>(a.pk);
     fill_qin<MT>(qin, ldq, a.tw, a.tb, a.h_lower, a.node_feat, a.lower_ids, a.lower_map, i0, nl, Fn, Dq, wave, lane);
     __syncthreads();
-    // q = W_q q_in (bias-free, models/modules.py:126)
-    stream_kc<MT>(pk + (size_t)a.off_q * 64, (Dq + 15) >> 4, (Dq + 15) >> 4, wave, lane, ldq, [&](int) { return (const float*)qin; }, [&](int t, const f4 (&acc)[MT]) {
-        const int n = 16 * t + 4 * g;
-        if (n < Dq) {
+    // q_h = W_q,h q_in (bias-free, models/modules.py:126); tile = 16 rows of the head
+    const int ntq = (hd + 15) >> 4;
+    stream4<MT>(pk + (size_t)a.off_q * 64, ntq, (Dq + 15) >> 4, wave, lane, ldq, [&](int) { return (const float*)qin; }, [&](int t, const f4 (&acc)[MT]) {
+        const int n = 16 * t + 4 * ng;
+        if (ks == 0 && n < ldh) {
 #pragma unroll
-            for (int j = 0; j < MT; ++j) *reinterpret_cast<f4*>(q + (16 * j + c) * ldq + n) = acc[j];
+            for (int m = 0; m < MT; ++m) *reinterpret_cast<f4*>(q + (4 * m + j) * ldh + n) = acc[m];
         }
-    });
+    }, [&](int t) { return h * ntq + t; });
     __syncthreads();
-    // qk[i][h][:] = W_k,h^T q_ih: rows h*hd .. of key_w [Dq][Dkv] are the contraction index; tile = (head, 64-wide block of Dkv)
-    const int nblk = (Dkv + 63) >> 6;
-    stream_km<MT>(pk + (size_t)a.off_k * 64, H * nblk, (hd + 3) >> 2, wave, lane, ldq, [&](int t) { return (const float*)q + (t / nblk) * hd; },
-                  [&](int t, const f4 (&acc)[4][MT]) {
-        const int h = t / nblk, nb = (t - h * nblk) * 64;
+    // qk[i][h][:] = W_k,h^T q_ih: rows h*hd .. of key_w [Dq][Dkv] are the contraction index; tile = 16 columns of Dkv
+    const int ntk = (Dkv + 15) >> 4;
+    stream4<MT>(pk + (size_t)a.off_k * 64, ntk, (hd + 15) >> 4, wave, lane, ldh, [&](int) { return (const float*)q; }, [&](int t, const f4 (&acc)[MT]) {
+        const int n = 16 * t + 4 * ng;
+        if (ks == 0 && n < Dkv) {
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const int64_t i = i0 + 16 * j + c;
-            if (i >= nl) continue;
-            float* o = a.qk + ((size_t)i * H + h) * Dkv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = nb + 16 * g + 4 * r;
-                if (n < Dkv) *reinterpret_cast<f4*>(o + n) = f4{acc[0][j][r], acc[1][j][r], acc[2][j][r], acc[3][j][r]};
+            for (int m = 0; m < MT; ++m) {
+                const int64_t i = i0 + 4 * m + j;
+                if (i < nl) *reinterpret_cast<f4*>(a.qk + ((size_t)i * H + h) * Dkv + n) = acc[m];
             }
         }
-    });
+    }, [&](int t) { return h * ntk + t; });
 }
 
-struct PostLds { int ldz, ldq, ldm, ldh, r0, total; };
+struct PostLds { int ldz, ldq, ldm, ldh, r0, par, total; };
 __host__ __device__ inline PostLds post_layout(int R, int Fn, int Ft, int Dkv, int H) {
     PostLds y;
     const int Dq = Fn + Ft;
     y.ldz = pad_ld((H - 1) * Dkv + r16(Dkv));
-    y.ldq = pad_ld(r16(Dq));
-    y.ldm = pad_ld(r16(Dq + Fn));
-    y.ldh = pad_ld(r16(Fn));
+    y.ldq = pad_ld(Dq);
+    y.ldm = pad_ld(Dq + Fn);
+    y.ldh = pad_ld(Fn);
     const int a = R * y.ldz, b = R * (y.ldq + y.ldm);
     y.r0 = a > b ? a : b;                       // region 0: z rows, later (z is dead after the W_v product) q_in rows | MergeLayer input rows
     const int r1 = R * (y.ldq > y.ldh ? y.ldq : y.ldh);      // region 1: att rows, later hid rows
-    y.total = y.r0 + r1;
+    y.par = y.r0 + r1;                          // then the bias / LayerNorm vectors: res_b | ln_w | ln_b (3 Dq) | fc1_b | fc2_b (2 Fn)
+    y.total = y.par + 3 * Dq + 2 * Fn;
     return y;
 }
 
@@ -341,8 +326,8 @@ template <int MT>
 __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 15, g = lane >> 4;
-    constexpr int R = 16 * MT;
+    const int j = lane & 3, ks = (lane >> 2) & 3, ng = lane >> 4;
+    constexpr int R = 4 * MT;
     const int64_t i0 = (int64_t)blockIdx.x * R;
     const int64_t nl = a.n_live ? (int64_t)*a.n_live : a.n;
     if (i0 >= nl) return;
@@ -354,7 +339,14 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
     float* mrg = lds + R * ldq;
     float* att = lds + L.r0;
     float* hid = att;
+    float* res_b = lds + L.par;
+    float* ln_w = res_b + Dq;
+    float* ln_b = ln_w + Dq;
+    float* fc1_b = ln_b + Dq;
+    float* fc2_b = fc1_b + Fn;
     const f4* pk = reinterpret_cast<const f4*>(a.pk);
+    for (int f = threadIdx.x; f < Dq; f += kThreads) { res_b[f] = a.res_b[f]; ln_w[f] = a.ln_w[f]; ln_b[f] = a.ln_b[f]; }
+    for (int f = threadIdx.x; f < Fn; f += kThreads) { fc1_b[f] = a.fc1_b[f]; fc2_b[f] = a.fc2_b[f]; }
     {   // z rows of the block (float4, coalesced); rows beyond the live count and the padding columns are zero
         const int z4 = (H * Dkv) >> 2, l4 = ldz >> 2;
         for (int rr = wave; rr < R; rr += kWaves) {
@@ -368,26 +360,26 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
     __syncthreads();
     // att[i][h*hd + e] = W_v,h z_ih (value_w [Dq][Dkv], bias-free); tile = (head, 16 rows of the head)
     const int nth = (hd + 15) >> 4;
-    stream_kc<MT>(pk + (size_t)a.off_v * 64, H * nth, (Dkv + 15) >> 4, wave, lane, ldz, [&](int t) { return (const float*)zb + (t / nth) * Dkv; },
-                  [&](int t, const f4 (&acc)[MT]) {
-        const int h = t / nth, n = (t - h * nth) * 16 + 4 * g;
-        if (n < hd) {
+    stream4<MT>(pk + (size_t)a.off_v * 64, H * nth, (Dkv + 15) >> 4, wave, lane, ldz, [&](int t) { return (const float*)zb + (t / nth) * Dkv; },
+                [&](int t, const f4 (&acc)[MT]) {
+        const int h = t / nth, n = (t - h * nth) * 16 + 4 * ng;
+        if (ks == 0 && n < hd) {
 #pragma unroll
-            for (int j = 0; j < MT; ++j) *reinterpret_cast<f4*>(att + (16 * j + c) * ldq + h * hd + n) = acc[j];
+            for (int m = 0; m < MT; ++m) *reinterpret_cast<f4*>(att + (4 * m + j) * ldq + h * hd + n) = acc[m];
         }
     });
     __syncthreads();
     fill_qin<MT>(qin, ldq, a.tw, a.tb, a.h_lower, a.node_feat, a.lower_ids, a.lower_map, i0, nl, Fn, Dq, wave, lane);      // the residual (models/modules.py:150, :196)
     __syncthreads();
     // x = residual_fc(att) + q_in, into the MergeLayer input rows (normalised in place below)
-    stream_kc<MT>(pk + (size_t)a.off_r * 64, (Dq + 15) >> 4, (Dq + 15) >> 4, wave, lane, ldq, [&](int) { return (const float*)att; }, [&](int t, const f4 (&acc)[MT]) {
-        const int n = 16 * t + 4 * g;
-        if (n < Dq) {
-            const f4 b = *reinterpret_cast<const f4*>(a.res_b + n);
+    stream4<MT>(pk + (size_t)a.off_r * 64, (Dq + 15) >> 4, (Dq + 15) >> 4, wave, lane, ldq, [&](int) { return (const float*)att; }, [&](int t, const f4 (&acc)[MT]) {
+        const int n = 16 * t + 4 * ng;
+        if (ks == 0 && n < Dq) {
+            const f4 b = *reinterpret_cast<const f4*>(res_b + n);
 #pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                const f4 r = *reinterpret_cast<const f4*>(qin + (16 * j + c) * ldq + n);
-                *reinterpret_cast<f4*>(mrg + (16 * j + c) * ldm + n) = f4{acc[j].x + b.x + r.x, acc[j].y + b.y + r.y, acc[j].z + b.z + r.z, acc[j].w + b.w + r.w};
+            for (int m = 0; m < MT; ++m) {
+                const f4 r = *reinterpret_cast<const f4*>(qin + (4 * m + j) * ldq + n);
+                *reinterpret_cast<f4*>(mrg + (4 * m + j) * ldm + n) = f4{acc[m].x + b.x + r.x, acc[m].y + b.y + r.y, acc[m].z + b.z + r.z, acc[m].w + b.w + r.w};
             }
         }
     });
@@ -410,7 +402,7 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         const float rstd = 1.0f / sqrtf(v / (float)Dq + 1e-5f);
-        for (int f = lane; f < Dq; f += 64) row[f] = (row[f] - mean) * rstd * a.ln_w[f] + a.ln_b[f];
+        for (int f = lane; f < Dq; f += 64) row[f] = (row[f] - mean) * rstd * ln_w[f] + ln_b[f];
         if (Fn <= 192) {
 #pragma unroll
             for (int x = 0; x < 3; ++x)
@@ -423,40 +415,47 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
     __syncthreads();
     // hid = relu(fc1 [y | raw] + b1)
     const int ntf = (Fn + 15) >> 4;
-    stream_kc<MT>(pk + (size_t)a.off_f1 * 64, ntf, (Dm + 15) >> 4, wave, lane, ldm, [&](int) { return (const float*)mrg; }, [&](int t, const f4 (&acc)[MT]) {
-        const int n = 16 * t + 4 * g;
-        if (n < Fn) {
-            const f4 b = *reinterpret_cast<const f4*>(a.fc1_b + n);
+    stream4<MT>(pk + (size_t)a.off_f1 * 64, ntf, (Dm + 15) >> 4, wave, lane, ldm, [&](int) { return (const float*)mrg; }, [&](int t, const f4 (&acc)[MT]) {
+        const int n = 16 * t + 4 * ng;
+        if (ks == 0 && n < Fn) {
+            const f4 b = *reinterpret_cast<const f4*>(fc1_b + n);
 #pragma unroll
-            for (int j = 0; j < MT; ++j)
-                *reinterpret_cast<f4*>(hid + (16 * j + c) * ldh + n) = f4{fmaxf(acc[j].x + b.x, 0.f), fmaxf(acc[j].y + b.y, 0.f), fmaxf(acc[j].z + b.z, 0.f), fmaxf(acc[j].w + b.w, 0.f)};
+            for (int m = 0; m < MT; ++m)
+                *reinterpret_cast<f4*>(hid + (4 * m + j) * ldh + n) = f4{fmaxf(acc[m].x + b.x, 0.f), fmaxf(acc[m].y + b.y, 0.f), fmaxf(acc[m].z + b.z, 0.f), fmaxf(acc[m].w + b.w, 0.f)};
         }
     });
     __syncthreads();
     // out = fc2 hid + b2
-    stream_kc<MT>(pk + (size_t)a.off_f2 * 64, ntf, (Fn + 15) >> 4, wave, lane, ldh, [&](int) { return (const float*)hid; }, [&](int t, const f4 (&acc)[MT]) {
-        const int n = 16 * t + 4 * g;
-        if (n < Fn) {
-            const f4 b = *reinterpret_cast<const f4*>(a.fc2_b + n);
+    stream4<MT>(pk + (size_t)a.off_f2 * 64, ntf, (Fn + 15) >> 4, wave, lane, ldh, [&](int) { return (const float*)hid; }, [&](int t, const f4 (&acc)[MT]) {
+        const int n = 16 * t + 4 * ng;
+        if (ks == 0 && n < Fn) {
+            const f4 b = *reinterpret_cast<const f4*>(fc2_b + n);
 #pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                const int64_t i = i0 + 16 * j + c;
-                if (i < nl) *reinterpret_cast<f4*>(a.out + (size_t)i * Fn + n) = f4{acc[j].x + b.x, acc[j].y + b.y, acc[j].z + b.z, acc[j].w + b.w};
+            for (int m = 0; m < MT; ++m) {
+                const int64_t i = i0 + 4 * m + j;
+                if (i < nl) *reinterpret_cast<f4*>(a.out + (size_t)i * Fn + n) = f4{acc[m].x + b.x, acc[m].y + b.y, acc[m].z + b.z, acc[m].w + b.w};
             }
         }
     });
 }
 
-// Workgroups 0 .. ceil(count/16)-1: the GRU rows.  The workgroups behind them: feat0 = memory + raw for the nodes of the call WITHOUT a
-// pending message (list2), one row per wave and round -- independent of the GRU rows, so it rides in the same launch.
+// grid = (row blocks + 8, slices).  Row blocks 0 .. ceil(count/R)-1: the GRU rows; slice s of a row block owns the memory dims
+// f in [16 ft0, 16 ft1) of ALL THREE gates (gate g, tile ft = packed tile g*ntf + ft), so the slices of a row block share nothing but the
+// gathered rows and a row block's weight stream is split over kGruSlices CUs.  The workgroups behind the row blocks (slice 0 only):
+// feat0 = memory + raw for the nodes of the call WITHOUT a pending message (list2), one row per wave and round -- independent of the
+// GRU rows, so it rides in the same launch.
+constexpr int kGruSlices = 6;
+template <int MT>
 __global__ __launch_bounds__(kThreads) void k_tgn_gru_chain(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 15, g = lane >> 4;
+    const int j = lane & 3, ks = (lane >> 2) & 3, ng = lane >> 4;
+    constexpr int R = 4 * MT;
     const int64_t cnt = *a.count;
-    const int64_t ngru = (cnt + 15) >> 4;
-    const int Dm = a.Dm, Fn = a.Fn, G = 3 * Fn;
+    const int64_t ngru = (cnt + R - 1) / R;
+    const int Dm = a.Dm, Fn = a.Fn;
     if ((int64_t)blockIdx.x >= ngru) {
+        if (blockIdx.y != 0) return;
         const int64_t cnt2 = *a.count2, nb = (int64_t)gridDim.x - ngru, F4 = Fn >> 2;
         for (int64_t r = ((int64_t)blockIdx.x - ngru) * kWaves + wave; r < cnt2; r += nb * kWaves) {
             const int64_t node = a.list2[r];
@@ -467,62 +466,66 @@ __global__ __launch_bounds__(kThreads) void k_tgn_gru_chain(const GruArgs a) {
         }
         return;
     }
-    const int64_t r0 = (int64_t)blockIdx.x * 16;
-    const int ldm = pad_ld(r16(Dm)), ldh = pad_ld(r16(Fn)), ldg = pad_ld(G);
-    float* am = lds;                  // [16][ldm] aggregated (= last) message rows
-    float* ah = am + 16 * ldm;        // [16][ldh] memory rows
-    float* gi = ah + 16 * ldh;        // [16][ldg] W_ih m + b_ih
-    float* gh = gi + 16 * ldg;        // [16][ldg] W_hh h + b_hh
+    const int ntf = (Fn + 15) >> 4, per = (ntf + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int ft0 = blockIdx.y * per, ft1 = ft0 + per < ntf ? ft0 + per : ntf, nft = ft1 - ft0;
+    if (nft <= 0) return;
+    const int64_t r0 = (int64_t)blockIdx.x * R;
+    const int ldm = pad_ld(Dm), ldh = pad_ld(Fn), ldg = 3 * per * 16;
+    float* am = lds;                  // [R][ldm] aggregated (= last) message rows
+    float* ah = am + R * ldm;         // [R][ldh] memory rows
+    float* gi = ah + R * ldh;         // [R][ldg] (W_ih m + b_ih)[gate][f of the slice]: column (gate * nft + ft - ft0) * 16 + f % 16
+    float* gh = gi + R * ldg;         // [R][ldg] W_hh h + b_hh
     const f4* pk = reinterpret_cast<const f4*>(a.pk);
-    {
-        int64_t node[2]; bool valid[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) { valid[r] = r0 + wave + 8 * r < cnt; node[r] = valid[r] ? a.list[r0 + wave + 8 * r] : 0; }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int rr = wave + 8 * r;
-            for (int f = lane; f < ldm; f += 64) am[rr * ldm + f] = (valid[r] && f < Dm) ? a.msg[node[r] * Dm + f] : 0.f;
-            for (int f = lane; f < ldh; f += 64) ah[rr * ldh + f] = (valid[r] && f < Fn) ? a.M[node[r] * Fn + f] : 0.f;
-        }
+    for (int rr = wave; rr < R; rr += kWaves) {
+        const bool valid = r0 + rr < cnt;
+        const int64_t node = valid ? a.list[r0 + rr] : 0;
+        for (int f = lane; f < ldm; f += 64) am[rr * ldm + f] = (valid && f < Dm) ? a.msg[node * Dm + f] : 0.f;
+        for (int f = lane; f < ldh; f += 64) ah[rr * ldh + f] = (valid && f < Fn) ? a.M[node * Fn + f] : 0.f;
     }
     __syncthreads();
-    const int nt = (G + 15) >> 4;
-    stream_kc<1>(pk + (size_t)a.off_ih * 64, nt, (Dm + 15) >> 4, wave, lane, ldm, [&](int) { return (const float*)am; }, [&](int t, const f4 (&acc)[1]) {
-        const int n = 16 * t + 4 * g;
-        if (n < G) {
-            const f4 b = *reinterpret_cast<const f4*>(a.b_ih + n);
-            *reinterpret_cast<f4*>(gi + c * ldg + n) = f4{acc[0].x + b.x, acc[0].y + b.y, acc[0].z + b.z, acc[0].w + b.w};
+    auto tmap = [&](int t) { return (t / nft) * ntf + ft0 + t % nft; };
+    stream4<MT>(pk + (size_t)a.off_ih * 64, 3 * nft, (Dm + 15) >> 4, wave, lane, ldm, [&](int) { return (const float*)am; }, [&](int t, const f4 (&acc)[MT]) {
+        if (ks == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) *reinterpret_cast<f4*>(gi + (4 * m + j) * ldg + 16 * t + 4 * ng) = acc[m];
         }
-    });
-    stream_kc<1>(pk + (size_t)a.off_hh * 64, nt, (Fn + 15) >> 4, kWaves - 1 - wave, lane, ldh, [&](int) { return (const float*)ah; },      // waves in reverse: evens the odd tile out
-                 [&](int t, const f4 (&acc)[1]) {
-        const int n = 16 * t + 4 * g;
-        if (n < G) {
-            const f4 b = *reinterpret_cast<const f4*>(a.b_hh + n);
-            *reinterpret_cast<f4*>(gh + c * ldg + n) = f4{acc[0].x + b.x, acc[0].y + b.y, acc[0].z + b.z, acc[0].w + b.w};
+    }, tmap);
+    stream4<MT>(pk + (size_t)a.off_hh * 64, 3 * nft, (Fn + 15) >> 4, kWaves - 1 - wave, lane, ldh, [&](int) { return (const float*)ah; },      // waves in reverse: evens the odd tile out
+                [&](int t, const f4 (&acc)[MT]) {
+        if (ks == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) *reinterpret_cast<f4*>(gh + (4 * m + j) * ldg + 16 * t + 4 * ng) = acc[m];
         }
-    });
+    }, tmap);
     __syncthreads();
     // nn.GRUCell gates (r, z, n order) -> new memory; feat0 = new memory + raw features (MemoryModel.py:609)
-    for (int idx = threadIdx.x; idx < 16 * Fn; idx += kThreads) {
-        const int rr = idx / Fn, f = idx - rr * Fn;
+    const int f_lo = 16 * ft0, f_hi = 16 * ft1 < Fn ? 16 * ft1 : Fn, fw = f_hi - f_lo;
+    for (int idx = threadIdx.x; idx < R * fw; idx += kThreads) {
+        const int rr = idx / fw, fl = idx - rr * fw, f = f_lo + fl;
         if (r0 + rr >= cnt) continue;
         const int64_t node = a.list[r0 + rr];
         const float* x = gi + rr * ldg;
         const float* y = gh + rr * ldg;
+        const int c0 = fl, c1 = nft * 16 + fl, c2 = 2 * nft * 16 + fl;
         const float h = ah[rr * ldh + f];
-        const float rg = 1.0f / (1.0f + expf(-(x[f] + y[f])));
-        const float zg = 1.0f / (1.0f + expf(-(x[Fn + f] + y[Fn + f])));
-        const float ng = tanhf(x[2 * Fn + f] + rg * y[2 * Fn + f]);
-        const float hn = (1.0f - zg) * ng + zg * h;
+        const float xr = x[c0] + a.b_ih[f], yr = y[c0] + a.b_hh[f];
+        const float xz = x[c1] + a.b_ih[Fn + f], yz = y[c1] + a.b_hh[Fn + f];
+        const float xn = x[c2] + a.b_ih[2 * Fn + f], yn = y[c2] + a.b_hh[2 * Fn + f];
+        const float rg = 1.0f / (1.0f + expf(-(xr + yr)));
+        const float zg = 1.0f / (1.0f + expf(-(xz + yz)));
+        const float ng_ = tanhf(xn + rg * yn);
+        const float hn = (1.0f - zg) * ng_ + zg * h;
         a.Mnew[node * Fn + f] = hn;
         a.feat0[node * Fn + f] = hn + a.raw[node * Fn + f];
     }
 }
 
-static size_t pre_lds(int Fn, int Ft, int MT) { return (size_t)2 * 16 * MT * pad_ld(r16(Fn + Ft)) * sizeof(float); }
-static size_t post_lds(int Fn, int Ft, int Dkv, int H, int MT) { return (size_t)post_layout(16 * MT, Fn, Ft, Dkv, H).total * sizeof(float); }
-static size_t gru_lds(const GruArgs& a) { return (size_t)16 * (pad_ld(r16(a.Dm)) + pad_ld(r16(a.Fn)) + 2 * pad_ld(3 * a.Fn)) * sizeof(float); }
+static size_t pre_lds(int Fn, int Ft, int H, int MT) { return (size_t)4 * MT * (pad_ld(Fn + Ft) + pad_ld((Fn + Ft) / H)) * sizeof(float); }
+static size_t post_lds(int Fn, int Ft, int Dkv, int H, int MT) { return (size_t)post_layout(4 * MT, Fn, Ft, Dkv, H).total * sizeof(float); }
+static size_t gru_lds(const GruArgs& a, int MT) {
+    const int per = ((a.Fn + 15) / 16 + kGruSlices - 1) / kGruSlices;
+    return (size_t)4 * MT * (pad_ld(a.Dm) + pad_ld(a.Fn) + 2 * 3 * per * 16) * sizeof(float);
+}
 constexpr size_t kLdsMax = 160 * 1024;
 
 template <class K>
@@ -530,45 +533,68 @@ static int set_lds(K kernel, size_t bytes) {
     if (bytes > 64 * 1024) DYGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return DYGNN_OK;
 }
-static int pick_mt(int64_t n, size_t lds2) { return (n > 4096 && lds2 <= kLdsMax) ? 2 : 1; }
+// Rows per workgroup = 4 MT.  Small levels take few rows so that they still spread over the chip (the weights are re-streamed from L2 by
+// every workgroup: 4 rows at 800 rows = 200 workgroups); large levels take 32 rows (every weight fragment feeds 32 MFMAs).  A row's
+// bits do not depend on the choice.
+static int pick_mt(int64_t n) { return n <= 2048 ? 1 : n <= 8192 ? 2 : 4; }
+static int env_mt(const char* name, int mt) {          // DYGNN_CHAIN_MT / DYGNN_GRU_MT = 1 | 2 | 4 | 8: tuning override (read per call)
+    const char* e = getenv(name);
+    if (e && (e[0] == '1' || e[0] == '2' || e[0] == '4' || e[0] == '8') && e[1] == 0) return e[0] - '0';
+    return mt;
+}
 
 bool fits(int Fn, int Ft, int Dkv, int H) {
     if (H < 1 || (Fn + Ft) % H || Fn % 4 || Ft % 4 || Dkv % 4 || ((Fn + Ft) / H) % 4) return false;
-    return pre_lds(Fn, Ft, 1) <= kLdsMax && post_lds(Fn, Ft, Dkv, H, 1) <= kLdsMax;
+    return pre_lds(Fn, Ft, H, 1) <= kLdsMax && post_lds(Fn, Ft, Dkv, H, 1) <= kLdsMax;
 }
 
+template <int MT>
+static int launch_pre_mt(hipStream_t s, const PreArgs& a) {
+    const size_t bytes = pre_lds(a.Fn, a.Ft, a.H, MT);
+    if (int rc = set_lds(k_tgat_pre<MT>, bytes)) return rc;
+    hipLaunchKernelGGL(k_tgat_pre<MT>, dim3((unsigned)ceil_div(a.n, 4 * MT), (unsigned)a.H), dim3(kThreads), bytes, s, a);
+    DYGNN_LAUNCH_CHECK();
+    return DYGNN_OK;
+}
 int launch_pre(hipStream_t s, const PreArgs& a) {
     if (a.n == 0) return DYGNN_OK;
     DYGNN_REQUIRE(fits(a.Fn, a.Ft, a.Dkv, a.H), "tgat chain: feature dims do not fit the row-block kernels");
-    const int MT = pick_mt(a.n, pre_lds(a.Fn, a.Ft, 2));
-    const size_t bytes = pre_lds(a.Fn, a.Ft, MT);
-    const dim3 grid((unsigned)ceil_div(a.n, 16 * MT));
-    if (MT == 2) { if (int rc = set_lds(k_tgat_pre<2>, bytes)) return rc; hipLaunchKernelGGL(k_tgat_pre<2>, grid, dim3(kThreads), bytes, s, a); }
-    else { if (int rc = set_lds(k_tgat_pre<1>, bytes)) return rc; hipLaunchKernelGGL(k_tgat_pre<1>, grid, dim3(kThreads), bytes, s, a); }
+    int MT = env_mt("DYGNN_CHAIN_MT", pick_mt(a.n));
+    while (MT > 1 && pre_lds(a.Fn, a.Ft, a.H, MT) > kLdsMax) MT >>= 1;
+    return MT == 8 ? launch_pre_mt<8>(s, a) : MT == 4 ? launch_pre_mt<4>(s, a) : MT == 2 ? launch_pre_mt<2>(s, a) : launch_pre_mt<1>(s, a);
+}
+
+template <int MT>
+static int launch_post_mt(hipStream_t s, const PostArgs& a) {
+    const size_t bytes = post_lds(a.Fn, a.Ft, a.Dkv, a.H, MT);
+    if (int rc = set_lds(k_tgat_post<MT>, bytes)) return rc;
+    hipLaunchKernelGGL(k_tgat_post<MT>, dim3((unsigned)ceil_div(a.n, 4 * MT)), dim3(kThreads), bytes, s, a);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }
-
 int launch_post(hipStream_t s, const PostArgs& a) {
     if (a.n == 0) return DYGNN_OK;
     DYGNN_REQUIRE(fits(a.Fn, a.Ft, a.Dkv, a.H), "tgat chain: feature dims do not fit the row-block kernels");
-    const int MT = pick_mt(a.n, post_lds(a.Fn, a.Ft, a.Dkv, a.H, 2));
-    const size_t bytes = post_lds(a.Fn, a.Ft, a.Dkv, a.H, MT);
-    const dim3 grid((unsigned)ceil_div(a.n, 16 * MT));
-    if (MT == 2) { if (int rc = set_lds(k_tgat_post<2>, bytes)) return rc; hipLaunchKernelGGL(k_tgat_post<2>, grid, dim3(kThreads), bytes, s, a); }
-    else { if (int rc = set_lds(k_tgat_post<1>, bytes)) return rc; hipLaunchKernelGGL(k_tgat_post<1>, grid, dim3(kThreads), bytes, s, a); }
+    int MT = env_mt("DYGNN_CHAIN_MT", pick_mt(a.n));
+    while (MT > 1 && post_lds(a.Fn, a.Ft, a.Dkv, a.H, MT) > kLdsMax) MT >>= 1;
+    return MT == 8 ? launch_post_mt<8>(s, a) : MT == 4 ? launch_post_mt<4>(s, a) : MT == 2 ? launch_post_mt<2>(s, a) : launch_post_mt<1>(s, a);
+}
+
+template <int MT>
+static int launch_gru_mt(hipStream_t s, const GruArgs& a) {
+    const size_t bytes = gru_lds(a, MT);
+    if (int rc = set_lds(k_tgn_gru_chain<MT>, bytes)) return rc;
+    hipLaunchKernelGGL(k_tgn_gru_chain<MT>, dim3((unsigned)ceil_div(a.max_rows, 4 * MT) + 8, kGruSlices), dim3(kThreads), bytes, s, a);      // + 8: always some workgroups for the plain rows
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }
-
 int launch_gru(hipStream_t s, const GruArgs& a) {
     if (a.max_rows == 0) return DYGNN_OK;
-    const size_t bytes = gru_lds(a);
-    DYGNN_REQUIRE(bytes <= kLdsMax && a.Fn % 4 == 0 && a.Dm % 4 == 0, "tgn chain: feature dims too large for the GRU row-block kernel (%zu bytes of LDS)", bytes);
-    if (int rc = set_lds(k_tgn_gru_chain, bytes)) return rc;
-    hipLaunchKernelGGL(k_tgn_gru_chain, dim3((unsigned)ceil_div(a.max_rows, 16) + 8), dim3(kThreads), bytes, s, a);      // + 8: always some workgroups for the plain rows
-    DYGNN_LAUNCH_CHECK();
-    return DYGNN_OK;
+    DYGNN_REQUIRE(gru_lds(a, 1) <= kLdsMax && a.Fn % 4 == 0 && a.Dm % 4 == 0, "tgn chain: feature dims too large for the GRU row-block kernel");
+    int MT = env_mt("DYGNN_GRU_MT", pick_mt(a.max_rows / 8));      // the list is a fraction of the level-0 set
+    if (MT > 4) MT = 4;
+    while (MT > 1 && gru_lds(a, MT) > kLdsMax) MT >>= 1;
+    return MT == 4 ? launch_gru_mt<4>(s, a) : MT == 2 ? launch_gru_mt<2>(s, a) : launch_gru_mt<1>(s, a);
 }
 
 }  // namespace chain

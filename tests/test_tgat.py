@@ -128,6 +128,37 @@ def test_hip_rows_do_not_depend_on_the_batch_they_are_in():
 
 
 @pytest.mark.gpu
+def test_hip_rows_do_not_depend_on_the_rows_per_workgroup(monkeypatch):
+    """the row-block chains (tgat_chain.hip: the layer form of TGN calls, DYGNN_TGAT_CHAIN=1 selects it for TGAT) give a workgroup 4, 8, 16 or
+    32 rows depending on the level size; a row's bits are the same for every choice (DYGNN_CHAIN_MT forces one), and TGAT's own
+    product-by-product GEMM form agrees to rounding"""
+    from dyglib_amd import TGAT, get_neighbor_sampler
+    data, nf, ef = syn.make_bipartite_graph(500, 60, 30000, seed=31)
+    nf[1:] = np.random.RandomState(5).standard_normal(nf[1:].shape).astype(np.float32) * 0.5
+    sampler = get_neighbor_sampler(data, "recent", seed=1, device="cuda:0")
+    m = TGAT(nf, ef, sampler, 100, num_layers=2, num_heads=2, dropout=0.1, device="cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_tgat_params(9).items()})
+    m = m.to("cuda:0").eval()
+    idx = np.arange(data.num_interactions - 203, data.num_interactions)          # 406 roots: not a multiple of any block size
+    src, dst, t = data.src_node_ids[idx], data.dst_node_ids[idx], data.node_interact_times[idx]
+    outs = {}
+    with torch.no_grad():
+        monkeypatch.setenv("DYGNN_TGAT_CHAIN", "1")
+        for mt in ("1", "2", "4", "8"):
+            monkeypatch.setenv("DYGNN_CHAIN_MT", mt)
+            outs[mt] = m.compute_src_dst_node_temporal_embeddings(src, dst, t, num_neighbors=20)
+        monkeypatch.delenv("DYGNN_CHAIN_MT")
+        auto = m.compute_src_dst_node_temporal_embeddings(src, dst, t, num_neighbors=20)
+        monkeypatch.delenv("DYGNN_TGAT_CHAIN")
+        gemm = m.compute_src_dst_node_temporal_embeddings(src, dst, t, num_neighbors=20)
+    for mt in ("2", "4", "8"):
+        assert torch.equal(outs["1"][0], outs[mt][0]) and torch.equal(outs["1"][1], outs[mt][1]), mt
+    assert torch.equal(outs["1"][0], auto[0]) and torch.equal(outs["1"][1], auto[1])
+    close(auto[0].cpu().numpy(), gemm[0].cpu().numpy(), "chain vs GEMM path src")
+    close(auto[1].cpu().numpy(), gemm[1].cpu().numpy(), "chain vs GEMM path dst")
+
+
+@pytest.mark.gpu
 def test_hip_level_deduplication_changes_nothing(monkeypatch):
     """two-layer `recent` TGAT computes every distinct (node, time) entry of level 1 once (k_dedup_*): the result is bit-identical to
     computing all of them (DYGNN_TGAT_DEDUP=0), on a batch where most level-1 entries are duplicates"""
