@@ -745,7 +745,14 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
         const size_t lds = (size_t)4 * p.H * p.k * sizeof(float);
         if (p.k <= 20 && p.H <= 2 && p.Dkv <= 512) {
             const int TW = 4 * ((p.Ft / 4 + 1) / 2);
-            const size_t lds2 = ((size_t)8 * p.H * 20 + (size_t)4 * 20 * TW) * sizeof(float);
+            // KC = the row slots a lane keeps in registers: 10 for k <= 10 (TGN's configuration; half the gathers of the 20-slot form, whose
+            // idle slots re-read row 0), 20 otherwise.  Idle slots contribute exact zeros, so a row's bits do not depend on KC.
+            const int KC = p.k <= 10 ? 10 : 20;
+            const size_t lds2 = ((size_t)8 * p.H * KC + (size_t)4 * KC * TW) * sizeof(float);
+            if (KC == 10)
+                hipLaunchKernelGGL((k_tgat_attn_pair<10>), dim3((unsigned)ceil_div(n, 2)), dim3(256), lds2, s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]),
+                                   F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z), nl, lmap);
+            else
             hipLaunchKernelGGL((k_tgat_attn_pair<20>), dim3((unsigned)ceil_div(n, 2)), dim3(256), lds2, s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]),
                                F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z), nl, lmap);
         } else if (p.k <= 20)

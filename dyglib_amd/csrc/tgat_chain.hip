@@ -162,70 +162,83 @@ int pack(hipStream_t s, const PackPlan& p, int L, int Fn, int Ft, int Dkv, int H
 constexpr int U = 8;
 
 struct IdTile { __device__ __forceinline__ int operator()(int t) const { return t; } };
-// TM: local tile index -> tile index in the packed stage (a workgroup that owns a slice of a stage's tiles)
-template <int MT, class AF, class Ep, class TM = IdTile>
-__device__ __forceinline__ void stream4(const f4* __restrict__ pk, int T, int nch, int wave, int lane, int lda, AF actf, Ep ep, TM tmap = TM()) {
-    if (wave >= T) return;
-    const int j = lane & 3, ks = (lane >> 2) & 3;
-    const int S = ((T - wave + kWaves - 1) / kWaves) * nch;
-    const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
-    int pt = wave, pch = 0;                                           // prefetch cursor
-    const f4* pp = pk + (size_t)tmap(wave) * nch * 64 + lane;
+// TM: local tile index -> tile index in the packed stage (a workgroup that owns a slice of a stage's tiles).
+// start() issues the first U fragment loads -- they depend on nothing the kernel computes, so a stage's ring is started BEFORE the
+// previous stage runs (its loads are then older than that stage's refills and have landed when it ends); run() consumes.
+template <class TM>
+struct WStream {
+    const f4* pk;
+    int T, nch, wave, lane, pt, pch;
+    const f4* pp;
+    TM tmap;
     f4 ring[U];
-    auto fetch = [&](f4& dst) {
+    __device__ __forceinline__ WStream(const f4* pk_, int T_, int nch_, int wave_, int lane_, TM tm) : pk(pk_), T(T_), nch(nch_), wave(wave_), lane(lane_), pt(wave_), pch(0), tmap(tm) {
+        pp = pk + (size_t)tmap(wave < T ? wave : 0) * nch * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < U; ++u) fetch(ring[u]);
+    }
+    __device__ __forceinline__ void fetch(f4& dst) {
         dst = *pp;
         pp += 64;
-        if (++pch == nch) { pch = 0; pt += kWaves; pp = pk + (size_t)tmap(pt < T ? pt : wave) * nch * 64 + lane; }
-    };
-#pragma unroll
-    for (int u = 0; u < U; ++u) fetch(ring[u]);
-    int ct = wave, cch = 0;                                           // consume cursor
-    const float* ab = actf(ct) + j * lda + 4 * ks;
-    f4 acc[MT], bn[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) { acc[m] = zero; bn[m] = *reinterpret_cast<const f4*>(ab + m * 4 * lda); }
-    auto step = [&](f4& slot, bool refill) {
-        const f4 w = slot;
-        f4 b[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) b[m] = bn[m];
-        const bool tile_end = cch + 1 == nch;
-        const int nt = tile_end ? ct + kWaves : ct, nc = tile_end ? 0 : cch + 1;
-        const float* nab = tile_end ? actf(nt < T ? nt : ct) + j * lda + 4 * ks : ab;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) bn[m] = *reinterpret_cast<const f4*>(nab + m * 4 * lda + 16 * nc);      // (behind the last step: a valid, unused read)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = mfma4(w.x, b[m].x, acc[m]);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = mfma4(w.y, b[m].y, acc[m]);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = mfma4(w.z, b[m].z, acc[m]);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = mfma4(w.w, b[m].w, acc[m]);
-        if (refill) fetch(slot);
-        if (tile_end) {
-            f4 r[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {          // k-slices 0 + 1, 2 + 3, then the pairs: fixed order
-                f4 v = acc[m];
-                v.x += __shfl_xor(v.x, 4, 64); v.y += __shfl_xor(v.y, 4, 64); v.z += __shfl_xor(v.z, 4, 64); v.w += __shfl_xor(v.w, 4, 64);
-                v.x += __shfl_xor(v.x, 8, 64); v.y += __shfl_xor(v.y, 8, 64); v.z += __shfl_xor(v.z, 8, 64); v.w += __shfl_xor(v.w, 8, 64);
-                r[m] = v;
-                acc[m] = zero;
-            }
-            ep(ct, r);
-        }
-        ct = nt; cch = nc; ab = nab;
-    };
-    int s0 = 0;
-    for (; s0 + U <= S; s0 += U) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) step(ring[u], true);
+        if (++pch == nch) { pch = 0; pt += kWaves; pp = pk + (size_t)tmap(pt < T ? pt : (wave < T ? wave : 0)) * nch * 64 + lane; }
     }
+    template <int MT, class AF, class Ep>
+    __device__ __forceinline__ void run(int lda, AF actf, Ep ep) {
+        if (wave >= T) return;
+        const int j = lane & 3, ks = (lane >> 2) & 3;
+        const int S = ((T - wave + kWaves - 1) / kWaves) * nch;
+        const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+        int ct = wave, cch = 0;                                           // consume cursor
+        const float* ab = actf(ct) + j * lda + 4 * ks;
+        f4 acc[MT], bn[MT];
 #pragma unroll
-    for (int u = 0; u < U - 1; ++u)
-        if (s0 + u < S) step(ring[u], false);
-}
+        for (int m = 0; m < MT; ++m) { acc[m] = zero; bn[m] = *reinterpret_cast<const f4*>(ab + m * 4 * lda); }
+        auto step = [&](f4& slot, bool refill) {
+            const f4 w = slot;
+            f4 b[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) b[m] = bn[m];
+            const bool tile_end = cch + 1 == nch;
+            const int nt = tile_end ? ct + kWaves : ct, nc = tile_end ? 0 : cch + 1;
+            const float* nab = tile_end ? actf(nt < T ? nt : ct) + j * lda + 4 * ks : ab;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) bn[m] = *reinterpret_cast<const f4*>(nab + m * 4 * lda + 16 * nc);      // (behind the last step: a valid, unused read)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma4(w.x, b[m].x, acc[m]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma4(w.y, b[m].y, acc[m]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma4(w.z, b[m].z, acc[m]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma4(w.w, b[m].w, acc[m]);
+            if (refill) fetch(slot);
+            if (tile_end) {
+                f4 r[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {          // k-slices 0 + 1, 2 + 3, then the pairs: fixed order
+                    f4 v = acc[m];
+                    v.x += __shfl_xor(v.x, 4, 64); v.y += __shfl_xor(v.y, 4, 64); v.z += __shfl_xor(v.z, 4, 64); v.w += __shfl_xor(v.w, 4, 64);
+                    v.x += __shfl_xor(v.x, 8, 64); v.y += __shfl_xor(v.y, 8, 64); v.z += __shfl_xor(v.z, 8, 64); v.w += __shfl_xor(v.w, 8, 64);
+                    r[m] = v;
+                    acc[m] = zero;
+                }
+                ep(ct, r);
+            }
+            ct = nt; cch = nc; ab = nab;
+        };
+        int s0 = 0;
+        for (; s0 + U <= S; s0 += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) step(ring[u], true);
+        }
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (s0 + u < S) step(ring[u], false);
+    }
+};
+template <class TM>
+__device__ __forceinline__ WStream<TM> wstream(const f4* pk, int T, int nch, int wave, int lane, TM tm) { return WStream<TM>(pk, T, nch, wave, lane, tm); }
+__device__ __forceinline__ WStream<IdTile> wstream(const f4* pk, int T, int nch, int wave, int lane) { return WStream<IdTile>(pk, T, nch, wave, lane, IdTile()); }
 
 // query-input rows [h(self) | cos(w*0 + b)] of the block's rows into LDS (zero rows beyond the live count; zero padding columns).
 // A wave owns rows wave, wave + 8, ...: their indices are loaded together, then their feature rows, column slot by column slot.
@@ -280,21 +293,22 @@ __global__ __launch_bounds__(kThreads) void k_tgat_pre(const PreArgs a) {
     float* qin = lds;
     float* q = qin + R * ldq;                 // [R][ldh]: this head's q, zero beyond hd (zero-packed weight rows)
     const f4* pk = reinterpret_cast<const f4*>(a.pk);
+    const int ntq = (hd + 15) >> 4, ntk = (Dkv + 15) >> 4;
+    auto sq = wstream(pk + (size_t)a.off_q * 64, ntq, (Dq + 15) >> 4, wave, lane, [=](int t) { return h * ntq + t; });
     fill_qin<MT>(qin, ldq, a.tw, a.tb, a.h_lower, a.node_feat, a.lower_ids, a.lower_map, i0, nl, Fn, Dq, wave, lane);
     __syncthreads();
+    auto sk = wstream(pk + (size_t)a.off_k * 64, ntk, (hd + 15) >> 4, wave, lane, [=](int t) { return h * ntk + t; });
     // q_h = W_q,h q_in (bias-free, models/modules.py:126); tile = 16 rows of the head
-    const int ntq = (hd + 15) >> 4;
-    stream4<MT>(pk + (size_t)a.off_q * 64, ntq, (Dq + 15) >> 4, wave, lane, ldq, [&](int) { return (const float*)qin; }, [&](int t, const f4 (&acc)[MT]) {
+    sq.template run<MT>(ldq, [&](int) { return (const float*)qin; }, [&](int t, const f4 (&acc)[MT]) {
         const int n = 16 * t + 4 * ng;
         if (ks == 0 && n < ldh) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) *reinterpret_cast<f4*>(q + (4 * m + j) * ldh + n) = acc[m];
         }
-    }, [&](int t) { return h * ntq + t; });
+    });
     __syncthreads();
     // qk[i][h][:] = W_k,h^T q_ih: rows h*hd .. of key_w [Dq][Dkv] are the contraction index; tile = 16 columns of Dkv
-    const int ntk = (Dkv + 15) >> 4;
-    stream4<MT>(pk + (size_t)a.off_k * 64, ntk, (hd + 15) >> 4, wave, lane, ldh, [&](int) { return (const float*)q; }, [&](int t, const f4 (&acc)[MT]) {
+    sk.template run<MT>(ldh, [&](int) { return (const float*)q; }, [&](int t, const f4 (&acc)[MT]) {
         const int n = 16 * t + 4 * ng;
         if (ks == 0 && n < Dkv) {
 #pragma unroll
@@ -303,7 +317,7 @@ __global__ __launch_bounds__(kThreads) void k_tgat_pre(const PreArgs a) {
                 if (i < nl) *reinterpret_cast<f4*>(a.qk + ((size_t)i * H + h) * Dkv + n) = acc[m];
             }
         }
-    }, [&](int t) { return h * ntk + t; });
+    });
 }
 
 struct PostLds { int ldz, ldq, ldm, ldh, r0, par, total; };
@@ -345,6 +359,8 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
     float* fc1_b = ln_b + Dq;
     float* fc2_b = fc1_b + Fn;
     const f4* pk = reinterpret_cast<const f4*>(a.pk);
+    const int nth = (hd + 15) >> 4, ntf = (Fn + 15) >> 4;
+    auto sv = wstream(pk + (size_t)a.off_v * 64, H * nth, (Dkv + 15) >> 4, wave, lane);
     for (int f = threadIdx.x; f < Dq; f += kThreads) { res_b[f] = a.res_b[f]; ln_w[f] = a.ln_w[f]; ln_b[f] = a.ln_b[f]; }
     for (int f = threadIdx.x; f < Fn; f += kThreads) { fc1_b[f] = a.fc1_b[f]; fc2_b[f] = a.fc2_b[f]; }
     {   // z rows of the block (float4, coalesced); rows beyond the live count and the padding columns are zero
@@ -358,10 +374,9 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
         }
     }
     __syncthreads();
+    auto sr = wstream(pk + (size_t)a.off_r * 64, (Dq + 15) >> 4, (Dq + 15) >> 4, wave, lane);
     // att[i][h*hd + e] = W_v,h z_ih (value_w [Dq][Dkv], bias-free); tile = (head, 16 rows of the head)
-    const int nth = (hd + 15) >> 4;
-    stream4<MT>(pk + (size_t)a.off_v * 64, H * nth, (Dkv + 15) >> 4, wave, lane, ldz, [&](int t) { return (const float*)zb + (t / nth) * Dkv; },
-                [&](int t, const f4 (&acc)[MT]) {
+    sv.template run<MT>(ldz, [&](int t) { return (const float*)zb + (t / nth) * Dkv; }, [&](int t, const f4 (&acc)[MT]) {
         const int h = t / nth, n = (t - h * nth) * 16 + 4 * ng;
         if (ks == 0 && n < hd) {
 #pragma unroll
@@ -372,7 +387,8 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
     fill_qin<MT>(qin, ldq, a.tw, a.tb, a.h_lower, a.node_feat, a.lower_ids, a.lower_map, i0, nl, Fn, Dq, wave, lane);      // the residual (models/modules.py:150, :196)
     __syncthreads();
     // x = residual_fc(att) + q_in, into the MergeLayer input rows (normalised in place below)
-    stream4<MT>(pk + (size_t)a.off_r * 64, (Dq + 15) >> 4, (Dq + 15) >> 4, wave, lane, ldq, [&](int) { return (const float*)att; }, [&](int t, const f4 (&acc)[MT]) {
+    auto sf1 = wstream(pk + (size_t)a.off_f1 * 64, ntf, (Dm + 15) >> 4, wave, lane);
+    sr.template run<MT>(ldq, [&](int) { return (const float*)att; }, [&](int t, const f4 (&acc)[MT]) {
         const int n = 16 * t + 4 * ng;
         if (ks == 0 && n < Dq) {
             const f4 b = *reinterpret_cast<const f4*>(res_b + n);
@@ -414,8 +430,8 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
     }
     __syncthreads();
     // hid = relu(fc1 [y | raw] + b1)
-    const int ntf = (Fn + 15) >> 4;
-    stream4<MT>(pk + (size_t)a.off_f1 * 64, ntf, (Dm + 15) >> 4, wave, lane, ldm, [&](int) { return (const float*)mrg; }, [&](int t, const f4 (&acc)[MT]) {
+    auto sf2 = wstream(pk + (size_t)a.off_f2 * 64, ntf, (Fn + 15) >> 4, wave, lane);
+    sf1.template run<MT>(ldm, [&](int) { return (const float*)mrg; }, [&](int t, const f4 (&acc)[MT]) {
         const int n = 16 * t + 4 * ng;
         if (ks == 0 && n < Fn) {
             const f4 b = *reinterpret_cast<const f4*>(fc1_b + n);
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
     });
     __syncthreads();
     // out = fc2 hid + b2
-    stream4<MT>(pk + (size_t)a.off_f2 * 64, ntf, (Fn + 15) >> 4, wave, lane, ldh, [&](int) { return (const float*)hid; }, [&](int t, const f4 (&acc)[MT]) {
+    sf2.template run<MT>(ldh, [&](int) { return (const float*)hid; }, [&](int t, const f4 (&acc)[MT]) {
         const int n = 16 * t + 4 * ng;
         if (ks == 0 && n < Fn) {
             const f4 b = *reinterpret_cast<const f4*>(fc2_b + n);
@@ -439,12 +455,13 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
     });
 }
 
-// grid = (row blocks + 8, slices).  Row blocks 0 .. ceil(count/R)-1: the GRU rows; slice s of a row block owns the memory dims
+// grid = (row-block workgroups + kPlainBlocks, slices).  The GRU rows: row blocks of R listed nodes, dealt round-robin to the row-block workgroups; slice s of a row block owns the memory dims
 // f in [16 ft0, 16 ft1) of ALL THREE gates (gate g, tile ft = packed tile g*ntf + ft), so the slices of a row block share nothing but the
 // gathered rows and a row block's weight stream is split over kGruSlices CUs.  The workgroups behind the row blocks (slice 0 only):
 // feat0 = memory + raw for the nodes of the call WITHOUT a pending message (list2), one row per wave and round -- independent of the
 // GRU rows, so it rides in the same launch.
-constexpr int kGruSlices = 6;
+constexpr int kGruSlices = 2;
+constexpr int kPlainBlocks = 64;      // x 8 waves = 512 plain rows per round
 template <int MT>
 __global__ __launch_bounds__(kThreads) void k_tgn_gru_chain(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -453,11 +470,13 @@ __global__ __launch_bounds__(kThreads) void k_tgn_gru_chain(const GruArgs a) {
     constexpr int R = 4 * MT;
     const int64_t cnt = *a.count;
     const int64_t ngru = (cnt + R - 1) / R;
+    const int64_t nrow = (int64_t)gridDim.x - kPlainBlocks;      // workgroups 0 .. nrow-1 walk the GRU row blocks, the last kPlainBlocks (and idle ones) the plain rows
     const int Dm = a.Dm, Fn = a.Fn;
-    if ((int64_t)blockIdx.x >= ngru) {
+    if ((int64_t)blockIdx.x >= (ngru < nrow ? ngru : nrow)) {
         if (blockIdx.y != 0) return;
-        const int64_t cnt2 = *a.count2, nb = (int64_t)gridDim.x - ngru, F4 = Fn >> 2;
-        for (int64_t r = ((int64_t)blockIdx.x - ngru) * kWaves + wave; r < cnt2; r += nb * kWaves) {
+        const int64_t first = ngru < nrow ? ngru : nrow;
+        const int64_t cnt2 = *a.count2, nb = (int64_t)gridDim.x - first, F4 = Fn >> 2;
+        for (int64_t r = ((int64_t)blockIdx.x - first) * kWaves + wave; r < cnt2; r += nb * kWaves) {
             const int64_t node = a.list2[r];
             for (int x = lane; x < F4; x += 64) {
                 const f4 m = *reinterpret_cast<const f4*>(a.M + node * Fn + 4 * x), w = *reinterpret_cast<const f4*>(a.raw + node * Fn + 4 * x);
@@ -469,61 +488,89 @@ __global__ __launch_bounds__(kThreads) void k_tgn_gru_chain(const GruArgs a) {
     const int ntf = (Fn + 15) >> 4, per = (ntf + (int)gridDim.y - 1) / (int)gridDim.y;
     const int ft0 = blockIdx.y * per, ft1 = ft0 + per < ntf ? ft0 + per : ntf, nft = ft1 - ft0;
     if (nft <= 0) return;
-    const int64_t r0 = (int64_t)blockIdx.x * R;
     const int ldm = pad_ld(Dm), ldh = pad_ld(Fn), ldg = 3 * per * 16;
     float* am = lds;                  // [R][ldm] aggregated (= last) message rows
     float* ah = am + R * ldm;         // [R][ldh] memory rows
-    float* gi = ah + R * ldh;         // [R][ldg] (W_ih m + b_ih)[gate][f of the slice]: column (gate * nft + ft - ft0) * 16 + f % 16
-    float* gh = gi + R * ldg;         // [R][ldg] W_hh h + b_hh
+    float* gi = ah + R * ldh;         // [R][ldg] (W_ih m)[gate][f of the slice]: column (gate * nft + ft - ft0) * 16 + f % 16
+    float* gh = gi + R * ldg;         // [R][ldg] W_hh h
     const f4* pk = reinterpret_cast<const f4*>(a.pk);
-    for (int rr = wave; rr < R; rr += kWaves) {
-        const bool valid = r0 + rr < cnt;
-        const int64_t node = valid ? a.list[r0 + rr] : 0;
-        for (int f = lane; f < ldm; f += 64) am[rr * ldm + f] = (valid && f < Dm) ? a.msg[node * Dm + f] : 0.f;
-        for (int f = lane; f < ldh; f += 64) ah[rr * ldh + f] = (valid && f < Fn) ? a.M[node * Fn + f] : 0.f;
-    }
-    __syncthreads();
-    auto tmap = [&](int t) { return (t / nft) * ntf + ft0 + t % nft; };
-    stream4<MT>(pk + (size_t)a.off_ih * 64, 3 * nft, (Dm + 15) >> 4, wave, lane, ldm, [&](int) { return (const float*)am; }, [&](int t, const f4 (&acc)[MT]) {
-        if (ks == 0) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) *reinterpret_cast<f4*>(gi + (4 * m + j) * ldg + 16 * t + 4 * ng) = acc[m];
-        }
-    }, tmap);
-    stream4<MT>(pk + (size_t)a.off_hh * 64, 3 * nft, (Fn + 15) >> 4, kWaves - 1 - wave, lane, ldh, [&](int) { return (const float*)ah; },      // waves in reverse: evens the odd tile out
-                [&](int t, const f4 (&acc)[MT]) {
-        if (ks == 0) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) *reinterpret_cast<f4*>(gh + (4 * m + j) * ldg + 16 * t + 4 * ng) = acc[m];
-        }
-    }, tmap);
-    __syncthreads();
-    // nn.GRUCell gates (r, z, n order) -> new memory; feat0 = new memory + raw features (MemoryModel.py:609)
+    auto tmap = [=](int t) { return (t / nft) * ntf + ft0 + t % nft; };
     const int f_lo = 16 * ft0, f_hi = 16 * ft1 < Fn ? 16 * ft1 : Fn, fw = f_hi - f_lo;
-    for (int idx = threadIdx.x; idx < R * fw; idx += kThreads) {
-        const int rr = idx / fw, fl = idx - rr * fw, f = f_lo + fl;
-        if (r0 + rr >= cnt) continue;
-        const int64_t node = a.list[r0 + rr];
-        const float* x = gi + rr * ldg;
-        const float* y = gh + rr * ldg;
-        const int c0 = fl, c1 = nft * 16 + fl, c2 = 2 * nft * 16 + fl;
-        const float h = ah[rr * ldh + f];
-        const float xr = x[c0] + a.b_ih[f], yr = y[c0] + a.b_hh[f];
-        const float xz = x[c1] + a.b_ih[Fn + f], yz = y[c1] + a.b_hh[Fn + f];
-        const float xn = x[c2] + a.b_ih[2 * Fn + f], yn = y[c2] + a.b_hh[2 * Fn + f];
-        const float rg = 1.0f / (1.0f + expf(-(xr + yr)));
-        const float zg = 1.0f / (1.0f + expf(-(xz + yz)));
-        const float ng_ = tanhf(xn + rg * yn);
-        const float hn = (1.0f - zg) * ng_ + zg * h;
-        a.Mnew[node * Fn + f] = hn;
-        a.feat0[node * Fn + f] = hn + a.raw[node * Fn + f];
+    for (int64_t blk = blockIdx.x; blk < ngru; blk += nrow) {      // (one round unless the list is longer than the grid's row blocks)
+        const int64_t r0 = blk * R;
+        auto si = wstream(pk + (size_t)a.off_ih * 64, 3 * nft, (Dm + 15) >> 4, wave, lane, tmap);
+        {   // the listed rows: a wave's node ids first, then float4 row pieces of all its rows in flight together
+            constexpr int RW = (R + kWaves - 1) / kWaves;
+            int64_t node[RW]; bool valid[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int rr = wave + kWaves * r;
+                valid[r] = rr < R && r0 + rr < cnt;
+                node[r] = valid[r] ? a.list[r0 + rr] : 0;
+            }
+            for (int x = lane; x < (ldm >> 2); x += 64) {
+                f4 v[RW];
+#pragma unroll
+                for (int r = 0; r < RW; ++r) v[r] = (4 * x < Dm) ? *reinterpret_cast<const f4*>(a.msg + node[r] * Dm + 4 * x) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+                    if (wave + kWaves * r < R) *reinterpret_cast<f4*>(am + (wave + kWaves * r) * ldm + 4 * x) = valid[r] ? v[r] : f4{0.f, 0.f, 0.f, 0.f};
+            }
+            for (int x = lane; x < (ldh >> 2); x += 64) {
+                f4 v[RW];
+#pragma unroll
+                for (int r = 0; r < RW; ++r) v[r] = (4 * x < Fn) ? *reinterpret_cast<const f4*>(a.M + node[r] * Fn + 4 * x) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+                    if (wave + kWaves * r < R) *reinterpret_cast<f4*>(ah + (wave + kWaves * r) * ldh + 4 * x) = valid[r] ? v[r] : f4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();
+        auto sh = wstream(pk + (size_t)a.off_hh * 64, 3 * nft, (Fn + 15) >> 4, kWaves - 1 - wave, lane, tmap);      // waves in reverse: evens the odd tile out
+        si.template run<MT>(ldm, [&](int) { return (const float*)am; }, [&](int t, const f4 (&acc)[MT]) {
+            if (ks == 0) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) *reinterpret_cast<f4*>(gi + (4 * m + j) * ldg + 16 * t + 4 * ng) = acc[m];
+            }
+        });
+        sh.template run<MT>(ldh, [&](int) { return (const float*)ah; }, [&](int t, const f4 (&acc)[MT]) {
+            if (ks == 0) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) *reinterpret_cast<f4*>(gh + (4 * m + j) * ldg + 16 * t + 4 * ng) = acc[m];
+            }
+        });
+        __syncthreads();
+        // nn.GRUCell gates (r, z, n order) -> new memory; feat0 = new memory + raw features (MemoryModel.py:609)
+        for (int idx = threadIdx.x; idx < R * fw; idx += kThreads) {
+            const int rr = idx / fw, fl = idx - rr * fw, f = f_lo + fl;
+            if (r0 + rr >= cnt) continue;
+            const int64_t node = a.list[r0 + rr];
+            const float* x = gi + rr * ldg;
+            const float* y = gh + rr * ldg;
+            const int c0 = fl, c1 = nft * 16 + fl, c2 = 2 * nft * 16 + fl;
+            const float h = ah[rr * ldh + f];
+            const float xr = x[c0] + a.b_ih[f], yr = y[c0] + a.b_hh[f];
+            const float xz = x[c1] + a.b_ih[Fn + f], yz = y[c1] + a.b_hh[Fn + f];
+            const float xn = x[c2] + a.b_ih[2 * Fn + f], yn = y[c2] + a.b_hh[2 * Fn + f];
+            const float rg = 1.0f / (1.0f + expf(-(xr + yr)));
+            const float zg = 1.0f / (1.0f + expf(-(xz + yz)));
+            const float ng_ = tanhf(xn + rg * yn);
+            const float hn = (1.0f - zg) * ng_ + zg * h;
+            a.Mnew[node * Fn + f] = hn;
+            a.feat0[node * Fn + f] = hn + a.raw[node * Fn + f];
+        }
+        __syncthreads();
     }
 }
 
 static size_t pre_lds(int Fn, int Ft, int H, int MT) { return (size_t)4 * MT * (pad_ld(Fn + Ft) + pad_ld((Fn + Ft) / H)) * sizeof(float); }
 static size_t post_lds(int Fn, int Ft, int Dkv, int H, int MT) { return (size_t)post_layout(4 * MT, Fn, Ft, Dkv, H).total * sizeof(float); }
+static int gru_slices() {          // DYGNN_GRU_SLICES = 1 .. 6: tuning override (read per call)
+    const char* e = getenv("DYGNN_GRU_SLICES");
+    return (e && e[0] >= '1' && e[0] <= '6' && e[1] == 0) ? e[0] - '0' : kGruSlices;
+}
 static size_t gru_lds(const GruArgs& a, int MT) {
-    const int per = ((a.Fn + 15) / 16 + kGruSlices - 1) / kGruSlices;
+    const int per = ((a.Fn + 15) / 16 + gru_slices() - 1) / gru_slices();
     return (size_t)4 * MT * (pad_ld(a.Dm) + pad_ld(a.Fn) + 2 * 3 * per * 16) * sizeof(float);
 }
 constexpr size_t kLdsMax = 160 * 1024;
@@ -584,7 +631,8 @@ template <int MT>
 static int launch_gru_mt(hipStream_t s, const GruArgs& a) {
     const size_t bytes = gru_lds(a, MT);
     if (int rc = set_lds(k_tgn_gru_chain<MT>, bytes)) return rc;
-    hipLaunchKernelGGL(k_tgn_gru_chain<MT>, dim3((unsigned)ceil_div(a.max_rows, 4 * MT) + 8, kGruSlices), dim3(kThreads), bytes, s, a);      // + 8: always some workgroups for the plain rows
+    const int64_t blocks = ceil_div(a.max_rows, 4 * MT);      // the list length is only known on the device: a bounded grid walks it
+    hipLaunchKernelGGL(k_tgn_gru_chain<MT>, dim3((unsigned)(blocks < 192 ? blocks : 192) + kPlainBlocks, gru_slices()), dim3(kThreads), bytes, s, a);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }
