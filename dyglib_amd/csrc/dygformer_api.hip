@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_merge_sigmoid_mfma(const float* __restr
 // The same head for a few hundred rows (one evaluation step: 400 .. 800): one workgroup = 16 rows, its 4 waves split the hidden units
 // (wave w: three 16-wide tiles from 48 w), so the rows' features and fc1 are read once per 16 rows instead of once per row (the
 // one-workgroup-per-row kernel moves hidden x 2 dim x 4 B = 237 KB of fc1 through L2 for EVERY row) and 50 workgroups run side by side
-// where the wave-per-16-rows form above would run 13.  Operands come straight from global memory / L2, four k-steps ahead in registers.
+// where the wave-per-16-rows form above would run 13.  Operands come straight from global memory / L2, eight k-steps ahead in registers.
 __global__ __launch_bounds__(256) void k_merge_sigmoid_mid(const float* __restrict__ a, const float* __restrict__ b, int64_t n_rows, int dim,
                                                              int hidden, const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w2, const float* __restrict__ b2,
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_merge_sigmoid_mid(const float* __restri
     const int64_t m = (int64_t)blockIdx.x * 16 + c;
     const bool mv = m < n_rows;
     const int K = 2 * dim, nsteps = (K + 15) >> 4;
-    constexpr int PF = 4;
+    constexpr int PF = 8;      // operand loads in flight per wave: 8 k-steps (the kernel is a chain of L2 round trips on 25-50 workgroups)
     const int n0 = 48 * wave;
     auto load_b = [&](int st) -> mf4 {
         const int kk = 16 * st + 4 * g;

@@ -766,7 +766,8 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
             // W_v z -> residual_fc + q_in -> LayerNorm -> MergeLayer, one workgroup per 16 / 32 rows
             const chain::LayerPack& y = pp.layer[l - 1];
             chain::PostArgs po{F32(p.z), h_lower, node_feat, I32(p.ids[l - 1]), lmap, nl, w->time_w, w->time_b, F32(p.pack), y.v, y.r, y.f1, y.f2, Lw.res_b, Lw.ln_w,
-                               Lw.ln_b, Lw.fc1_b, Lw.fc2_b, h_out, n, p.Fn, p.Ft, p.Dkv, p.H};
+                               Lw.ln_b, Lw.fc1_b, Lw.fc2_b, h_out, n, p.Fn, p.Ft, p.Dkv, p.H, nullptr};
+            if (const char* st_env = getenv("DYGNN_CHAIN_STAMPS")) po.stamps = reinterpret_cast<unsigned long long*>(strtoull(st_env, nullptr, 0));      // tools/chain_stamps.py
             if (int rc = chain::launch_post(s, po)) return rc;
             if (direct) return DYGNN_OK;
             continue;

@@ -67,6 +67,7 @@ struct PostArgs {
     float* out;                    // [n][Fn]
     int64_t n;
     int Fn, Ft, Dkv, H;
+    unsigned long long* stamps;    // diagnostic: s_memtime of wave 0 at the stage boundaries, 16 per workgroup (NULL: off)
 };
 int launch_post(hipStream_t s, const PostArgs& a);
 

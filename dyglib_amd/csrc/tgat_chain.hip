@@ -159,7 +159,10 @@ int pack(hipStream_t s, const PackPlan& p, int L, int Fn, int Ft, int Dkv, int H
 // s+1 are read before the MFMAs of step s.
 // AF: act(t) = LDS base of the activation operand of tile t.  Ep(t, acc): the finished tile -- every lane holds the sums of
 // Out[4m + j][16t + 4ng .. +3] in acc[m]; the ks == 0 lanes store.
-constexpr int U = 8;
+#ifndef DYGNN_CHAIN_U
+#define DYGNN_CHAIN_U 4      // ring depth: the chains run at the rate a CU streams fragments through its vector L1 (~35 B/clk measured), 4 .. 16 deep gave the same time per step; 4 is the least code
+#endif
+constexpr int U = DYGNN_CHAIN_U;
 
 struct IdTile { __device__ __forceinline__ int operator()(int t) const { return t; } };
 // TM: local tile index -> tile index in the packed stage (a workgroup that owns a slice of a stage's tiles).
@@ -168,19 +171,27 @@ struct IdTile { __device__ __forceinline__ int operator()(int t) const { return 
 template <class TM>
 struct WStream {
     const f4* pk;
-    int T, nch, wave, lane, pt, pch;
+    int T, nch, wave, lane, pt, pch, adv;
     const f4* pp;
     TM tmap;
     f4 ring[U];
     __device__ __forceinline__ WStream(const f4* pk_, int T_, int nch_, int wave_, int lane_, TM tm) : pk(pk_), T(T_), nch(nch_), wave(wave_), lane(lane_), pt(wave_), pch(0), tmap(tm) {
-        pp = pk + (size_t)tmap(wave < T ? wave : 0) * nch * 64 + lane;
+        adv = wave < T ? 64 : 0;
+        pp = wave < T ? pk + (size_t)tmap(wave) * nch * 64 + lane : pk;
 #pragma unroll
         for (int u = 0; u < U; ++u) fetch(ring[u]);
     }
+    // Behind the wave's last fragment every lane re-reads ONE address (a single 16-byte request): the refill stays unconditional -- the
+    // compiler keeps counting the loads in flight -- without fetching a junk KiB per step (U junk fragments per stage and wave were 10-70 %
+    // of these short streams' traffic).
     __device__ __forceinline__ void fetch(f4& dst) {
         dst = *pp;
-        pp += 64;
-        if (++pch == nch) { pch = 0; pt += kWaves; pp = pk + (size_t)tmap(pt < T ? pt : (wave < T ? wave : 0)) * nch * 64 + lane; }
+        pp += adv;
+        if (++pch == nch) {
+            pch = 0; pt += kWaves;
+            if (pt < T) pp = pk + (size_t)tmap(pt) * nch * 64 + lane;
+            else { pp = pk; adv = 0; }
+        }
     }
     template <int MT, class AF, class Ep>
     __device__ __forceinline__ void run(int lda, AF actf, Ep ep) {
@@ -240,41 +251,76 @@ template <class TM>
 __device__ __forceinline__ WStream<TM> wstream(const f4* pk, int T, int nch, int wave, int lane, TM tm) { return WStream<TM>(pk, T, nch, wave, lane, tm); }
 __device__ __forceinline__ WStream<IdTile> wstream(const f4* pk, int T, int nch, int wave, int lane) { return WStream<IdTile>(pk, T, nch, wave, lane, IdTile()); }
 
-// query-input rows [h(self) | cos(w*0 + b)] of the block's rows into LDS (zero rows beyond the live count; zero padding columns).
-// A wave owns rows wave, wave + 8, ...: their indices are loaded together, then their feature rows, column slot by column slot.
-template <int MT>
-__device__ __forceinline__ void fill_qin(float* qin, int ldq, const float* __restrict__ tw, const float* __restrict__ tb, const float* __restrict__ h_lower,
+// query-input rows [h(self) | cos(w*0 + b)] of the block's rows (zero rows beyond the live count; zero padding columns).
+// A wave owns rows wave, wave + 8, ...: load() takes their indices, then their feature rows (and, for k_tgat_post, the raw feature rows
+// of the MergeLayer input) into registers -- issued at the start of a kernel, two dependent round trips that overlap whatever comes
+// next; store() / store_raw() write them to LDS once the buffer is free.
+template <int MT, int NQ, bool RAW>
+struct RowRegs {
+    static constexpr int R = 4 * MT, RW = (R + kWaves - 1) / kWaves, NR = RAW ? NQ : 1;
+    float v[RW][NQ], rv[RW][NR];
+    bool valid[RW], have[RW];
+    __device__ __forceinline__ void load(const float* __restrict__ tw, const float* __restrict__ tb, const float* __restrict__ h_lower,
                                          const float* __restrict__ node_feat, const int32_t* __restrict__ lower_ids, const int32_t* __restrict__ lower_map,
                                          int64_t i0, int64_t nl, int Fn, int Dq, int wave, int lane) {
-    constexpr int R = 4 * MT, RW = (R + kWaves - 1) / kWaves;
-    const float* hsrc[RW];
-    bool valid[RW], have[RW];
+        const float* hsrc[RW];
+        const float* raw[RW];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        const int rr = wave + kWaves * r;
-        const int64_t i = i0 + rr;
-        have[r] = rr < R;
-        valid[r] = have[r] && i < nl;
-        int64_t idx = 0;
-        if (valid[r]) idx = h_lower ? (lower_map ? (int64_t)lower_map[i] : i) : (int64_t)lower_ids[i];
-        hsrc[r] = (h_lower ? h_lower : node_feat) + idx * Fn;
-    }
-    for (int f = lane; f < ldq; f += 64) {
-        if (f < Fn) {
-            float v[RW];
+        for (int r = 0; r < RW; ++r) {
+            const int rr = wave + kWaves * r;
+            const int64_t i = i0 + rr;
+            have[r] = rr < R;
+            valid[r] = have[r] && i < nl;
+            int64_t idx = 0, id = 0;
+            if (valid[r]) {
+                id = (!h_lower || RAW) ? (int64_t)lower_ids[i] : 0;
+                idx = h_lower ? (lower_map ? (int64_t)lower_map[i] : i) : id;
+            }
+            hsrc[r] = (h_lower ? h_lower : node_feat) + idx * Fn;
+            raw[r] = node_feat + id * Fn;
+        }
 #pragma unroll
-            for (int r = 0; r < RW; ++r) v[r] = hsrc[r][f];
+        for (int x = 0; x < NQ; ++x) {
+            const int f = lane + 64 * x;
+            if (f < Fn) {
 #pragma unroll
-            for (int r = 0; r < RW; ++r)
-                if (have[r]) qin[(wave + kWaves * r) * ldq + f] = valid[r] ? v[r] : 0.f;
-        } else {
-            const float v = f < Dq ? cosf(fmaf(0.0f, tw[f - Fn], tb[f - Fn])) : 0.f;      // the query's time feature: dt = 0 (models/TGAT.py:84)
+                for (int r = 0; r < RW; ++r) v[r][x] = hsrc[r][f];
+            } else {
+                const float c = f < Dq ? cosf(fmaf(0.0f, tw[f - Fn], tb[f - Fn])) : 0.f;      // the query's time feature: dt = 0 (models/TGAT.py:84)
 #pragma unroll
-            for (int r = 0; r < RW; ++r)
-                if (have[r]) qin[(wave + kWaves * r) * ldq + f] = valid[r] ? v : 0.f;
+                for (int r = 0; r < RW; ++r) v[r][x] = c;
+            }
+            if (RAW) {
+#pragma unroll
+                for (int r = 0; r < RW; ++r) rv[r][x] = f < Fn ? raw[r][f] : 0.f;
+            }
         }
     }
-}
+    __device__ __forceinline__ void store(float* qin, int ldq, int wave, int lane) const {
+#pragma unroll
+        for (int x = 0; x < NQ; ++x) {
+            const int f = lane + 64 * x;
+            if (f < ldq) {
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+                    if (have[r]) qin[(wave + kWaves * r) * ldq + f] = valid[r] ? v[r][x] : 0.f;
+            }
+        }
+    }
+    // the raw features behind the Dq LayerNorm outputs of the MergeLayer input rows, zero up to the row stride
+    __device__ __forceinline__ void store_raw(float* mrg, int ldm, int Dq, int wave, int lane) const {
+#pragma unroll
+        for (int x = 0; x < NR; ++x) {
+            const int f = lane + 64 * x;
+            if (Dq + f < ldm) {
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+                    if (have[r]) mrg[(wave + kWaves * r) * ldm + Dq + f] = valid[r] ? rv[r][x] : 0.f;
+            }
+        }
+    }
+};
+constexpr int kNQ = 5;      // column slots of 64 per row held in registers: row strides up to 320 floats (fits() checks)
 
 // grid = (row blocks, heads): a workgroup computes ONE head's q_h = W_q,h q_in and qk_h = W_k,h^T q_h (the heads share nothing but q_in,
 // which each re-reads), so a row block's weight stream is split over H CUs
@@ -295,7 +341,11 @@ __global__ __launch_bounds__(kThreads) void k_tgat_pre(const PreArgs a) {
     const f4* pk = reinterpret_cast<const f4*>(a.pk);
     const int ntq = (hd + 15) >> 4, ntk = (Dkv + 15) >> 4;
     auto sq = wstream(pk + (size_t)a.off_q * 64, ntq, (Dq + 15) >> 4, wave, lane, [=](int t) { return h * ntq + t; });
-    fill_qin<MT>(qin, ldq, a.tw, a.tb, a.h_lower, a.node_feat, a.lower_ids, a.lower_map, i0, nl, Fn, Dq, wave, lane);
+    {
+        RowRegs<MT, kNQ, false> rows;
+        rows.load(a.tw, a.tb, a.h_lower, a.node_feat, a.lower_ids, a.lower_map, i0, nl, Fn, Dq, wave, lane);
+        rows.store(qin, ldq, wave, lane);
+    }
     __syncthreads();
     auto sk = wstream(pk + (size_t)a.off_k * 64, ntk, (hd + 15) >> 4, wave, lane, [=](int t) { return h * ntk + t; });
     // q_h = W_q,h q_in (bias-free, models/modules.py:126); tile = 16 rows of the head
@@ -360,7 +410,15 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
     float* fc2_b = fc1_b + Fn;
     const f4* pk = reinterpret_cast<const f4*>(a.pk);
     const int nth = (hd + 15) >> 4, ntf = (Fn + 15) >> 4;
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + stamp_i] = __builtin_amdgcn_s_memtime();
+        ++stamp_i;
+    };
+    stamp();
     auto sv = wstream(pk + (size_t)a.off_v * 64, H * nth, (Dkv + 15) >> 4, wave, lane);
+    RowRegs<MT, kNQ, true> rows;      // residual rows and raw feature rows: requested now, used after the W_v product
+    rows.load(a.tw, a.tb, a.h_lower, a.node_feat, a.lower_ids, a.lower_map, i0, nl, Fn, Dq, wave, lane);
     for (int f = threadIdx.x; f < Dq; f += kThreads) { res_b[f] = a.res_b[f]; ln_w[f] = a.ln_w[f]; ln_b[f] = a.ln_b[f]; }
     for (int f = threadIdx.x; f < Fn; f += kThreads) { fc1_b[f] = a.fc1_b[f]; fc2_b[f] = a.fc2_b[f]; }
     {   // z rows of the block (float4, coalesced); rows beyond the live count and the padding columns are zero
@@ -374,6 +432,7 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
         }
     }
     __syncthreads();
+    stamp();
     auto sr = wstream(pk + (size_t)a.off_r * 64, (Dq + 15) >> 4, (Dq + 15) >> 4, wave, lane);
     // att[i][h*hd + e] = W_v,h z_ih (value_w [Dq][Dkv], bias-free); tile = (head, 16 rows of the head)
     sv.template run<MT>(ldz, [&](int t) { return (const float*)zb + (t / nth) * Dkv; }, [&](int t, const f4 (&acc)[MT]) {
@@ -384,8 +443,10 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
         }
     });
     __syncthreads();
-    fill_qin<MT>(qin, ldq, a.tw, a.tb, a.h_lower, a.node_feat, a.lower_ids, a.lower_map, i0, nl, Fn, Dq, wave, lane);      // the residual (models/modules.py:150, :196)
+    stamp();
+    rows.store(qin, ldq, wave, lane);      // the residual (models/modules.py:150, :196)
     __syncthreads();
+    stamp();
     // x = residual_fc(att) + q_in, into the MergeLayer input rows (normalised in place below)
     auto sf1 = wstream(pk + (size_t)a.off_f1 * 64, ntf, (Dm + 15) >> 4, wave, lane);
     sr.template run<MT>(ldq, [&](int) { return (const float*)att; }, [&](int t, const f4 (&acc)[MT]) {
@@ -400,14 +461,10 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
         }
     });
     __syncthreads();
+    stamp();
     // LayerNorm (eps 1e-5) per row; the raw node features fill the rest of the MergeLayer input (models/TGAT.py:134, models/modules.py:64)
     for (int rr = wave; rr < R; rr += kWaves) {
-        const int64_t i = i0 + rr;
         float* row = mrg + rr * ldm;
-        const float* raw = a.node_feat + (size_t)(i < nl ? a.lower_ids[i] : 0) * Fn;
-        float rv[3];
-#pragma unroll
-        for (int x = 0; x < 3; ++x) rv[x] = (lane + 64 * x < Fn) ? raw[lane + 64 * x] : 0.f;      // in flight during the reductions
         float s = 0.f;
         for (int f = lane; f < Dq; f += 64) s += row[f];
 #pragma unroll
@@ -419,16 +476,11 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         const float rstd = 1.0f / sqrtf(v / (float)Dq + 1e-5f);
         for (int f = lane; f < Dq; f += 64) row[f] = (row[f] - mean) * rstd * ln_w[f] + ln_b[f];
-        if (Fn <= 192) {
-#pragma unroll
-            for (int x = 0; x < 3; ++x)
-                if (lane + 64 * x < ldm - Dq) row[Dq + lane + 64 * x] = i < nl ? rv[x] : 0.f;
-        } else {
-            for (int f = lane; f < ldm - Dq; f += 64) row[Dq + f] = (i < nl && f < Fn) ? raw[f] : 0.f;
-        }
         for (int f = Fn + lane; f < ldh; f += 64) hid[rr * ldh + f] = 0.f;      // the hid rows' padding columns (att is dead)
     }
+    rows.store_raw(mrg, ldm, Dq, wave, lane);
     __syncthreads();
+    stamp();
     // hid = relu(fc1 [y | raw] + b1)
     auto sf2 = wstream(pk + (size_t)a.off_f2 * 64, ntf, (Fn + 15) >> 4, wave, lane);
     sf1.template run<MT>(ldm, [&](int) { return (const float*)mrg; }, [&](int t, const f4 (&acc)[MT]) {
@@ -441,6 +493,7 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
         }
     });
     __syncthreads();
+    stamp();
     // out = fc2 hid + b2
     sf2.template run<MT>(ldh, [&](int) { return (const float*)hid; }, [&](int t, const f4 (&acc)[MT]) {
         const int n = 16 * t + 4 * ng;
@@ -453,6 +506,7 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
             }
         }
     });
+    stamp();
 }
 
 // grid = (row-block workgroups + kPlainBlocks, slices).  The GRU rows: row blocks of R listed nodes, dealt round-robin to the row-block workgroups; slice s of a row block owns the memory dims
@@ -592,6 +646,7 @@ static int env_mt(const char* name, int mt) {          // DYGNN_CHAIN_MT / DYGNN
 
 bool fits(int Fn, int Ft, int Dkv, int H) {
     if (H < 1 || (Fn + Ft) % H || Fn % 4 || Ft % 4 || Dkv % 4 || ((Fn + Ft) / H) % 4) return false;
+    if (pad_ld(Fn + Ft) > 64 * kNQ || pad_ld(Fn + Ft + Fn) - (Fn + Ft) > 64 * kNQ) return false;      // RowRegs
     return pre_lds(Fn, Ft, H, 1) <= kLdsMax && post_lds(Fn, Ft, Dkv, H, 1) <= kLdsMax;
 }
 

@@ -190,3 +190,42 @@ def test_joint_step_equals_the_four_array_form():
             assert torch.equal(js[:n], ps) and torch.equal(jd[:n], pd) and torch.equal(js[n:], ns) and torch.equal(jd[n:], nd)
     assert torch.equal(four.memory_bank.node_memories, joint.memory_bank.node_memories)
     assert torch.equal(four.memory_bank.msg, joint.memory_bank.msg) and torch.equal(four.memory_bank.has_msg, joint.memory_bank.has_msg)
+
+
+@pytest.mark.gpu
+def test_rows_and_state_do_not_depend_on_the_workgroup_shapes(monkeypatch):
+    """The row-block kernels of a TGN call (tgat_chain.hip) pick rows per workgroup from the level size, and the GRU kernel splits the
+    memory dims into slices: rows and the memory bank left behind are bit-identical for every choice (DYGNN_CHAIN_MT / DYGNN_GRU_MT /
+    DYGNN_GRU_SLICES force one), and the layer's product-by-product GEMM form (DYGNN_TGAT_CHAIN=0) agrees to rounding."""
+    import numpy as np
+    import torch
+    from dyglib_amd import MemoryModel, get_neighbor_sampler
+    c = gc.build_tgn_case("tgn_bip_l1_k10")
+    cfg, d, dev = c["tgn_cfg"], c["data"], "cuda:0"
+
+    def run(env):
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        sampler = get_neighbor_sampler(d, "recent", seed=1, device=dev)
+        m = MemoryModel(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"], model_name="TGN", num_layers=cfg["num_layers"],
+                        num_heads=cfg["num_heads"], dropout=0.1, device=dev)
+        sd = m.state_dict(); sd.update({k: torch.from_numpy(v) for k, v in c["tgn_params"].items()}); m.load_state_dict(sd)
+        m = m.to(dev).eval()
+        m.memory_bank.__init_memory_bank__()
+        outs = []
+        with torch.no_grad():
+            for b in c["tgn_batches"]:
+                outs.append(torch.cat(m.compute_step_embeddings_joint(np.concatenate([b["src"], b["src"]]), np.concatenate([b["dst"], b["neg"]]),
+                                                                      np.concatenate([b["t"], b["t"]]), b["eid"], len(b["src"]), num_neighbors=cfg["num_neighbors"])))
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        return torch.cat(outs), m.memory_bank.node_memories.clone(), m.memory_bank.msg.clone()
+
+    base = run({})
+    for env in ({"DYGNN_CHAIN_MT": "2", "DYGNN_GRU_MT": "2", "DYGNN_GRU_SLICES": "1"}, {"DYGNN_CHAIN_MT": "4", "DYGNN_GRU_MT": "4", "DYGNN_GRU_SLICES": "3"},
+                {"DYGNN_CHAIN_MT": "8", "DYGNN_GRU_MT": "1", "DYGNN_GRU_SLICES": "6"}):
+        other = run(env)
+        assert all(torch.equal(x, y) for x, y in zip(base, other)), env
+    gemm = run({"DYGNN_TGAT_CHAIN": "0"})
+    close(base[0].cpu().numpy(), gemm[0].cpu().numpy(), "tgn chain vs GEMM form: rows")
+    close(base[1].cpu().numpy(), gemm[1].cpu().numpy(), "tgn chain vs GEMM form: memory")
