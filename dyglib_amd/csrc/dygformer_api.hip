@@ -111,79 +111,83 @@ __global__ __launch_bounds__(256) void k_merge_sigmoid_mfma(const float* __restr
 }
 
 
-// The same head for a few hundred rows (one evaluation step: 400 .. 800): one workgroup = 16 rows, its 4 waves split the hidden units
-// (wave w: three 16-wide tiles from 48 w), so the rows' features and fc1 are read once per 16 rows instead of once per row (the
-// one-workgroup-per-row kernel moves hidden x 2 dim x 4 B = 237 KB of fc1 through L2 for EVERY row) and 50 workgroups run side by side
-// where the wave-per-16-rows form above would run 13.  Operands come straight from global memory / L2, eight k-steps ahead in registers.
-__global__ __launch_bounds__(256) void k_merge_sigmoid_mid(const float* __restrict__ a, const float* __restrict__ b, int64_t n_rows, int dim,
-                                                             int hidden, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                             const float* __restrict__ w2, const float* __restrict__ b2,
-                                                             float* __restrict__ out, int sig) {
-    __shared__ float zpart[4][16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    const int64_t m = (int64_t)blockIdx.x * 16 + c;
-    const bool mv = m < n_rows;
-    const int K = 2 * dim, nsteps = (K + 15) >> 4;
-    constexpr int PF = 8;      // operand loads in flight per wave: 8 k-steps (the kernel is a chain of L2 round trips on 25-50 workgroups)
-    const int n0 = 48 * wave;
-    auto load_b = [&](int st) -> mf4 {
-        const int kk = 16 * st + 4 * g;
-        if (!(mv && kk < K)) return mf4{0.f, 0.f, 0.f, 0.f};
-        return kk < dim ? *reinterpret_cast<const mf4*>(a + m * dim + kk) : *reinterpret_cast<const mf4*>(b + m * dim + (kk - dim));
-    };
-    auto load_a = [&](int st, int i) -> mf4 {
-        const int kk = 16 * st + 4 * g, n = n0 + 16 * i + c;
-        return (n < hidden && kk < K) ? *reinterpret_cast<const mf4*>(w1 + (size_t)n * K + kk) : mf4{0.f, 0.f, 0.f, 0.f};
-    };
-    mf4 acc[3] = {mf4{0.f, 0.f, 0.f, 0.f}, mf4{0.f, 0.f, 0.f, 0.f}, mf4{0.f, 0.f, 0.f, 0.f}};
-    mf4 bq[PF], aq[PF][3];
+// The same head for a few hundred rows (one evaluation step: 400 .. 800).  FOUR rows per workgroup and one wave per 16-wide tile of hidden
+// units (hidden = 172: 11 waves), on `v_mfma_f32_4x4x1_16b_f32` used as 4 groups of hidden units x 4 slices of k against the four rows
+// (tgat_chain.hip has the long form of this): lane L = 16 ng + 4 ks + i holds fc1[16 wave + 4 ng + i][16 chunk + 4 ks ..] -- the 16 lanes of a
+// quarter-wave read 4 rows x 64 contiguous bytes (the 16x16x4 form: 16 rows x 16 bytes, four times the L1 lookups per byte) -- and
+// multiplies it with cat(a, b)[row j][16 chunk + 4 ks ..] out of LDS.  400 rows = 100 workgroups; a wave's stream is 22 steps.
+// (The previous form, 16 rows per workgroup with 4 waves over the hidden units, took 16 us for 400 rows on 25 workgroups: every wave's
+// float4 operand loads touched 16 rows, and 4 or 8 k-steps in flight made no difference.)
+__global__ __launch_bounds__(1024) void k_merge_sigmoid_rows4(const float* __restrict__ a, const float* __restrict__ b, int64_t n_rows, int dim,
+                                                               int hidden, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                               const float* __restrict__ w2, const float* __restrict__ b2,
+                                                               float* __restrict__ out, int sig, int ldx) {
+    extern __shared__ __attribute__((aligned(16))) float mlds[];
+    float* x = mlds;                      // [4][ldx] cat(a, b) rows, zero-padded to the 16-k chunk
+    float* zp = x + 4 * ldx;              // [waves][4] per-tile parts of the fc2 dot product
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int j = lane & 3, ks = (lane >> 2) & 3, ng = lane >> 4;
+    const int K = 2 * dim, nch = (K + 15) >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * 4;
+    const int n_lane = 16 * wave + 4 * ng + j;
+    const bool rowok = n_lane < hidden;
+    const float* wp = w1 + (size_t)(rowok ? n_lane : 0) * K + 4 * ks;
+    constexpr int PF = 4;
+    mf4 ring[PF];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        bq[u] = load_b(u);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) aq[u][i] = load_a(u, i);
+    for (int u = 0; u < PF; ++u) ring[u] = *reinterpret_cast<const mf4*>(wp + ((16 * u + 4 * ks < K) ? 16 * u : 0));
+    for (int rr = wave; rr < 4; rr += nwaves) {
+        const int64_t m = r0 + rr;
+        for (int f = lane; f < ldx; f += 64) x[rr * ldx + f] = (m < n_rows && f < K) ? (f < dim ? a[m * dim + f] : b[m * dim + (f - dim)]) : 0.f;
     }
-    for (int st0 = 0; st0 < nsteps; st0 += PF) {
+    __syncthreads();
+    mf4 acc = mf4{0.f, 0.f, 0.f, 0.f};
+    const float* xb = x + j * ldx + 4 * ks;
+    for (int c0 = 0; c0 < nch; c0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            if (st0 + u < nsteps) {
-                const mf4 bf = bq[u];
-                mf4 af[3];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) af[i] = aq[u][i];
-                bq[u] = load_b(st0 + u + PF);                  // beyond K: zeros, no access
-#pragma unroll
-                for (int i = 0; i < 3; ++i) aq[u][i] = load_a(st0 + u + PF, i);
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[t], acc[i], 0, 0, 0);
+            const int ch = c0 + u;
+            if (ch < nch) {
+                const bool kok = 16 * ch + 4 * ks < K;
+                const mf4 w = (rowok && kok) ? ring[u] : mf4{0.f, 0.f, 0.f, 0.f};
+                const mf4 xv = *reinterpret_cast<const mf4*>(xb + 16 * ch);
+                const int nx = ch + PF;
+                ring[u] = *reinterpret_cast<const mf4*>(wp + ((nx < nch && 16 * nx + 4 * ks < K) ? 16 * nx : 0));
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, xv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, xv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, xv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, xv.w, acc, 0, 0, 0);
             }
         }
     }
+    // k-slices 0 + 1, 2 + 3, then the pairs; then relu(h + b1) . w2 over the lane's four hidden units, the four groups, the tiles
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        acc[e] += __shfl_xor(acc[e], 4, 64);
+        acc[e] += __shfl_xor(acc[e], 8, 64);
+    }
     float z = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + 16 * i + 4 * g + r;
-            if (n < hidden) z = fmaf(fmaxf(acc[i][r] + b1[n], 0.f), w2[n], z);
-        }
+    for (int e = 0; e < 4; ++e) {
+        const int n = 16 * wave + 4 * ng + e;
+        if (n < hidden) z = fmaf(fmaxf(acc[e] + b1[n], 0.f), w2[n], z);
+    }
     z += __shfl_xor(z, 16, 64);
     z += __shfl_xor(z, 32, 64);
-    if (g == 0) zpart[wave][c] = z;
+    if (lane < 4) zp[wave * 4 + lane] = z;      // ng = 0, ks = 0, row j = lane
     __syncthreads();
-    if (wave == 0 && g == 0 && mv) {
-        const float z = ((zpart[0][c] + zpart[1][c]) + (zpart[2][c] + zpart[3][c])) + b2[0];
-        out[m] = sig ? 1.0f / (1.0f + expf(-z)) : z;
+    if (threadIdx.x < 4 && r0 + threadIdx.x < n_rows) {
+        float t = 0.f;
+        for (int w = 0; w < nwaves; ++w) t += zp[w * 4 + threadIdx.x];
+        t += b2[0];
+        out[r0 + threadIdx.x] = sig ? 1.0f / (1.0f + expf(-t)) : t;
     }
 }
 
 // Backward of the link predictor z = fc2(relu(fc1(cat(a, b)))) for the training step (train_link_prediction.py:241-257; models/modules.py:57-68):
 // given g = dL/dz [n] it produces da, db [n][dim] and ACCUMULATES the four parameter gradients (buffers zeroed by the caller).
 // k_merge_bwd_rows, one workgroup = 16 rows (the forward kernel above with a different ending):
-//   * hidden pre-activations on the matrix cores exactly as k_merge_sigmoid_mid (wave w: three 16-wide hidden tiles from 48 w);
+//   * hidden pre-activations on the matrix cores, 16 rows per workgroup (wave w: three 16-wide hidden tiles from 48 w);
 //   * dh = g w2 [pre > 0] leaves as rows [n][hidden] (the operand of the weight-gradient product below) and, transposed, into LDS; dfc2_w from the
 //     accumulators (DPP row sums, one atomic per hidden unit and workgroup), dfc2_b likewise;
 //   * dcat = dh fc1 on the matrix cores: out^T[k][row] = sum_j fc1[j][k] dh^T[j][row].  One float4 of an fc1 row (4 consecutive k) per lane feeds FOUR
@@ -409,9 +413,12 @@ static int merge_forward(const float* a, const float* b, int64_t n, int32_t dim,
         DYGNN_LAUNCH_CHECK();
         return DYGNN_OK;
     }
-    if (dim % 4 == 0 && hidden <= 192 && n >= 64) {     // an evaluation step's worth of rows
-        hipLaunchKernelGGL(k_merge_sigmoid_mid, dim3((unsigned)ceil_div(n, 16)), dim3(256), 0, as_stream(stream), a, b, n, dim, hidden,
-                           fc1_w, fc1_b, fc2_w, fc2_b, out, sig);
+    if (dim % 4 == 0 && hidden <= 256 && n >= 64) {     // an evaluation step's worth of rows
+        const int tiles = (hidden + 15) / 16, k16 = (2 * dim + 15) & ~15, ldx = (k16 & 16) ? k16 : k16 + 16;      // row stride % 32 == 16: the four rows on distinct banks
+        const size_t lds4 = ((size_t)4 * ldx + 4 * tiles) * sizeof(float);
+        DYGNN_REQUIRE(lds4 <= 64 * 1024, "merge_layer: dim too large");
+        hipLaunchKernelGGL(k_merge_sigmoid_rows4, dim3((unsigned)ceil_div(n, 4)), dim3(64 * tiles), lds4, as_stream(stream), a, b, n, dim, hidden,
+                           fc1_w, fc1_b, fc2_w, fc2_b, out, sig, ldx);
         DYGNN_LAUNCH_CHECK();
         return DYGNN_OK;
     }
