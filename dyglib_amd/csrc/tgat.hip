@@ -714,11 +714,17 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
     // with their weights packed).  Product by product through the general GEMM: TGAT's levels of 10^4..10^5 rows.  The choice depends on
     // the caller, never on the batch, so a row keeps its bits at every batch size; DYGNN_TGAT_CHAIN=0/1 forces one (A/B switch, read per call).
     const char* ch_env = getenv("DYGNN_TGAT_CHAIN");
-    const bool chain = (ch_env && (ch_env[0] == '0' || ch_env[0] == '1') ? ch_env[0] == '1' : packed) && chain::fits(p.Fn, p.Ft, p.Dkv, p.H);
+    // chain_from: the first layer that runs as chains.  TGN: all (1).  TGAT: none (L + 1); DYGNN_TGAT_CHAIN=1: all, =2: the top layer only (the
+    // roots: a few hundred rows per evaluation step) -- by layer, never by batch size.
+    const bool fits = chain::fits(p.Fn, p.Ft, p.Dkv, p.H);
+    int chain_from = packed ? 1 : p.L + 1;
+    if (ch_env && ch_env[0] >= '0' && ch_env[0] <= '2') chain_from = ch_env[0] == '0' ? p.L + 1 : ch_env[0] == '1' ? 1 : p.L;
+    if (!fits) chain_from = p.L + 1;
     const chain::PackPlan pp = chain::plan_pack(p.L, p.Fn, p.Ft, p.Dkv, p.H, 2 * p.Fn + p.Ft + p.Fe);
-    if (chain && !packed)
+    if (chain_from <= p.L && !packed)
         if (int rc = chain::pack(s, pp, p.L, p.Fn, p.Ft, p.Dkv, p.H, w, nullptr, 0, F32(p.pack))) return rc;
     for (int l = 1; l <= p.L; ++l) {
+        const bool chain = l >= chain_from;
         const dygnn_tgat_layer_weights& Lw = w->layers[l - 1];
         const int64_t n = p.n[l];
         const float* h_lower = l >= 2 ? F32(p.h[l - 1]) : nullptr;
