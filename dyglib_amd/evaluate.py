@@ -77,6 +77,7 @@ def evaluate_model_link_prediction(model_name: str, model: nn.Module, neighbor_s
     backbone, merge = model[0], model[1]
     plain_bce = _is_plain_bce(loss_func)
     results = []                                    # per launch: (ap, auc, loss, status) device tensors, in batch order
+    label_cache = {}
 
     def score(groups_pos, groups_neg):
         """groups_*: lists of equally sized (src, dst, t[, eid]) tuples -> predicts, labels [len, 2B]"""
@@ -113,8 +114,13 @@ def evaluate_model_link_prediction(model_name: str, model: nn.Module, neighbor_s
                 ps, pd, ns, nd = backbone.compute_step_embeddings(gp[0], gp[1], gn[0], gn[1], gp[2], gp[3], num_neighbors=num_neighbors)
                 probs.append(torch.stack([merge.link_probabilities(ps, pd), merge.link_probabilities(ns, nd)]))
             prob = torch.stack(probs, dim=1)
-        predicts = torch.cat([prob[0], prob[1]], dim=1)                                     # :142
-        labels = torch.cat([torch.ones_like(prob[0]), torch.zeros_like(prob[1])], dim=1)    # :143
+        G, Bp = prob.shape[1], prob.shape[2]
+        predicts = prob.permute(1, 0, 2).reshape(G, 2 * Bp)                                 # :142 cat([positive, negative]) per batch: a view for one batch per launch
+        key = (G, Bp, prob.device, prob.dtype)
+        labels = label_cache.get(key)                                                       # :143 [ones ; zeros]: the same tensor for every launch of a shape
+        if labels is None:
+            labels = label_cache[key] = torch.cat([torch.ones((G, Bp), device=prob.device, dtype=prob.dtype),
+                                                   torch.zeros((G, Bp), device=prob.device, dtype=prob.dtype)], dim=1)
         return predicts, labels
 
     def flush(pos, neg):
