@@ -549,8 +549,8 @@ def bench_tgn(dev, steps: int = 100, warmup: int = 60, cpu_budget_s: float = 10.
                         "frac": round(byts / sec_step / PEAK_HBM_BPS, 5), "traffic": None, "bytes_per_step": byts, "flop_per_step": flop,
                         "mfma_frac": round(flop / sec_step / (PEAK_F32_MFMA_TFLOPS * 1e12), 5),
                         "note": f"one 200-edge step is {byts / 1e6:.1f} MB and {flop / 1e9:.2f} GFLOP: {byts / PEAK_HBM_BPS * 1e6:.1f} us of HBM time, "
-                                f"{flop / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e6:.1f} us of MFMA time.  The step is seven dependent launches (expansion, "
-                                "list + weight packing, GRU, query / key chain, attention, value .. MergeLayer chain, commit) + the link predictor; the three "
+                                f"{flop / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e6:.1f} us of MFMA time.  The step is six dependent launches (expansion, "
+                                "list + weight packing, GRU, query / key chain, attention + value .. MergeLayer chain, commit) + the link predictor; the three "
                                 "row-block chains re-stream the layer's weights per 4-row block from L2 (what bounds them, DESIGN.md 4.6); both fractions "
                                 "are reported, neither is close to a roofline"}}
     if cpu_budget_s > 0:

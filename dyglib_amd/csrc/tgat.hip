@@ -12,6 +12,7 @@
 #include "common.h"
 #include "gemm.h"
 #include "tgat_chain.h"
+#include "tgat_attn.h"
 
 namespace dygnn {
 
@@ -119,27 +120,7 @@ __global__ __launch_bounds__(256) void k_tgat_inputs(const float* __restrict__ h
     }
 }
 
-__device__ __attribute__((noinline)) float cos_libm(float x) { return cosf(x); }
-__device__ __forceinline__ float cos_time_t(float x) {      // same range reduction + polynomial as dygformer_fused3.hip
-    if (!(fabsf(x) <= 3.0e7f)) return cos_libm(x);
-    const float INV_HI = 0.15915493667125702f, INV_LO = 6.4206382432985265e-09f;
-    const float p = x * INV_HI;
-    const float e = fmaf(x, INV_HI, -p);
-    const float q = fmaf(x, INV_LO, e);
-    const float t = (p - rintf(p)) + q;
-    float u = fabsf(t);
-    u = u > 0.5f ? 1.0f - u : u;
-    const bool flip = u > 0.25f;
-    const float v = flip ? 0.5f - u : u;
-    const float z = v * v;
-    float r = fmaf(7.903536371318467f, z, -26.42625678337438f);
-    r = fmaf(r, z, 60.24464137187666f);
-    r = fmaf(r, z, -85.45681720669373f);
-    r = fmaf(r, z, 64.93939402266829f);
-    r = fmaf(r, z, -19.739208802178716f);
-    r = fmaf(r, z, 1.0f);
-    return flip ? -r : r;
-}
+using attn::cos_time_t;
 
 // C[M][N] = act(A[M][K] . W[N][K]^T + bias): fp32 MFMA, operands straight from global memory (both are K-contiguous, so
 // lane (c,g) of a 16x16x4 fragment reads the float4 at [row c][k0 + 4g]); a wave computes a 64 x 64 block (4x4 tiles).
@@ -359,13 +340,7 @@ __global__ __launch_bounds__(256) void k_tgat_attn_lin(const float* __restrict__
     }
 }
 
-// The same attention with TWO waves per node (k <= KC, H <= 2, Dkv <= 512): wave `hf` of a pair owns the float4 columns
-// 2*lane + hf of the input rows, so a lane keeps KC float4 (80 VGPRs at k = 20) instead of 2*KC and four to five waves fit
-// on a SIMD where the one-wave form (255 VGPRs + spills around the libm call) fitted one; the kernel is bound by gather
-// latency, so occupancy is what pays.  Phases: (A) the pair's cosines, spread over the lanes, into LDS -- BEFORE any
-// gather is in flight, so the out-of-line libm fallback of cos_time_t has nothing live to spill; (B) all k gathers back to
-// back; (C) partial scores per half -> LDS -> workgroup barrier -> both waves run the same softmax on lanes (h, j);
-// (D) weighted sum of the cached rows.  Workgroup = 2 nodes.
+// The same attention with TWO waves per node (k <= KC, H <= 2, Dkv <= 512; tgat_attn.h: attn::pair_node).  Workgroup = 2 nodes.
 template <int KC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tgat_attn_pair(const float* __restrict__ qk, const float* __restrict__ h_lower, const float* __restrict__ node_feat,
                                                           const float* __restrict__ edge_feat, const int32_t* __restrict__ lower_ids,
@@ -374,102 +349,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                           float* __restrict__ z, const int32_t* __restrict__ n_live, const int32_t* __restrict__ lower_map) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hf = wave & 1, slot = wave >> 1;
-    int64_t i = (int64_t)blockIdx.x * 2 + slot;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int64_t i = (int64_t)blockIdx.x * 2 + (wave >> 1);
     const int64_t nl = n_live ? (int64_t)*n_live : n;      // entries in use (a de-duplicated level keeps the layout size n)
     if ((int64_t)blockIdx.x * 2 >= nl) return;              // whole workgroup beyond the live entries
     const bool live = i < nl;
     if (!live) i = nl - 1;                                  // keeps the barrier uniform; nothing is written
-    const int Dkv = Fn + Fe + Ft, D4 = Dkv >> 2, T0 = (Fn + Fe) >> 2, NT4 = Ft >> 2;
-    const int par = (hf - T0) & 1;                          // parity, inside the time block, of the time columns this half owns
-    const int ntc = (NT4 - par + 1) >> 1;                   // how many of them
-    const int TW = 4 * ((NT4 + 1) >> 1);                    // floats per row of the time staging area
-    float* part = reinterpret_cast<float*>(smem);                                   // [2 slots][2 halves][H][KC]
-    float* tf = part + 4 * H * KC + (size_t)wave * KC * TW;                         // [4 waves][KC][TW]
-    float* pw = part + 4 * H * KC + (size_t)4 * KC * TW + (size_t)wave * H * KC;    // [4 waves][H][KC]
-    const int64_t r0 = i * k;
-    // (A) time encodings of this half's columns for all k rows
-    if (lane < 4 * ntc) {
-        const int f = 4 * (2 * (lane >> 2) + par) + (lane & 3);
-        const float w = tw[f], b = tb[f];
-#pragma unroll 1
-        for (int j = 0; j < k; ++j) tf[j * TW + lane] = cos_time_t(fmaf(nbr_dt[r0 + j], w, b));
-    }
-    // (B) gathers
-    const int col = 2 * lane + hf, kk = 4 * col;
-    const bool vcol = col < D4;
-    const int cls = !vcol ? 3 : kk < Fn ? 0 : kk < Fn + Fe ? 1 : 2;
-    const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
-    f4 xs[KC];
-    if (cls <= 1) {
-        const float* bp = cls == 0 ? (h_lower ? h_lower : node_feat) + kk : edge_feat + (kk - Fn);
-        const size_t st = cls == 0 ? (size_t)Fn : (size_t)Fe;
-#pragma unroll
-        for (int j = 0; j < KC; ++j) {
-            const int64_t r = r0 + (j < k ? j : 0);
-            const int64_t nrow = h_lower ? (lower_map ? (int64_t)lower_map[n + r] : n + r) : (int64_t)lower_ids[n + r];
-            const int64_t erow = nbr_eid[r];
-            xs[j] = *reinterpret_cast<const f4*>(bp + (cls == 0 ? nrow : erow) * st);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < KC; ++j) xs[j] = zero;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (cls == 2) {
-        const int lt = (col - T0) >> 1;
-#pragma unroll
-        for (int j = 0; j < KC; ++j) xs[j] = *reinterpret_cast<const f4*>(tf + (j < k ? j : 0) * TW + 4 * lt);
-    }
-#pragma unroll
-    for (int j = 0; j < KC; ++j)
-        if (j >= k) xs[j] = zero;
-    // (C) partial scores of this half, all (row, head) reductions pipelined
-    auto dot4 = [](const f4 a, const f4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); };
-    for (int h = 0; h < H; ++h) {
-        const f4 q = vcol ? *reinterpret_cast<const f4*>(qk + ((size_t)i * H + h) * Dkv + kk) : zero;
-        float sc[KC];
-#pragma unroll
-        for (int j = 0; j < KC; ++j) sc[j] = dot4(q, xs[j]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int j = 0; j < KC; ++j) sc[j] += __shfl_xor(sc[j], o, 64);
-#pragma unroll
-        for (int j = 0; j < KC; ++j)
-            if (lane == j) part[((slot * 2 + hf) * H + h) * KC + j] = sc[j];
-    }
-    __syncthreads();
-    {   // softmax over the k neighbours: lane = 32 * head + row (modules.py:173 scale, :176-184 mask)
-        const int h = lane >> 5, j = lane & 31;
-        const bool on = h < H && j < k;
-        float s = -INFINITY;
-        if (on) {
-            s = (part[((slot * 2 + 0) * H + h) * KC + j] + part[((slot * 2 + 1) * H + h) * KC + j]) * scale;
-            if (lower_ids[n + r0 + j] == 0) s = -1e10f;
-        }
-        float mx = s;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        const float e = on ? expf(s - mx) : 0.f;
-        float sum = e;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        if (on) pw[h * KC + j] = e * (1.0f / sum);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // (D) z_ih = sum_j p_ijh x_ij for this half's columns
-    for (int h = 0; h < H; ++h) {
-        f4 za = zero;
-#pragma unroll
-        for (int j = 0; j < KC; ++j) {                 // no early exit: a break keeps xs[] from being promoted to registers
-            const float p = j < k ? pw[h * KC + j] : 0.f;
-            za.x = fmaf(p, xs[j].x, za.x); za.y = fmaf(p, xs[j].y, za.y); za.z = fmaf(p, xs[j].z, za.z); za.w = fmaf(p, xs[j].w, za.w);
-        }
-        if (vcol && live) *reinterpret_cast<f4*>(z + ((size_t)i * H + h) * Dkv + kk) = za;
-    }
+    const int Dkv = Fn + Fe + Ft;
+    attn::pair_node<KC>(qk, h_lower, node_feat, edge_feat, lower_ids, nbr_eid, nbr_dt, tw, tb, n, k, Fn, Fe, Ft, H, scale, lower_map, i, live, false, wave, 4, lane,
+                        reinterpret_cast<float*>(smem), z + (size_t)i * H * Dkv, Dkv);
 }
 
 // y = LayerNorm(fc_out + residual) (models/modules.py:196-199), written into the first Dq columns of the MergeLayer input
@@ -749,7 +637,9 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
         }
         const dim3 grid((unsigned)ceil_div(n, 4));
         const size_t lds = (size_t)4 * p.H * p.k * sizeof(float);
-        if (p.k <= 20 && p.H <= 2 && p.Dkv <= 512) {
+        const bool attn_in_post = chain && chain::post_fuses_attention(n, p.Fn, p.Ft, p.Dkv, p.H, p.k);      // the chain's last kernel runs it on its own rows
+        if (attn_in_post) {
+        } else if (p.k <= 20 && p.H <= 2 && p.Dkv <= 512) {
             const int TW = 4 * ((p.Ft / 4 + 1) / 2);
             // KC = the row slots a lane keeps in registers: 10 for k <= 10 (TGN's configuration; half the gathers of the 20-slot form, whose
             // idle slots re-read row 0), 20 otherwise.  Idle slots contribute exact zeros, so a row's bits do not depend on KC.
@@ -772,7 +662,8 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
             // W_v z -> residual_fc + q_in -> LayerNorm -> MergeLayer, one workgroup per 16 / 32 rows
             const chain::LayerPack& y = pp.layer[l - 1];
             chain::PostArgs po{F32(p.z), h_lower, node_feat, I32(p.ids[l - 1]), lmap, nl, w->time_w, w->time_b, F32(p.pack), y.v, y.r, y.f1, y.f2, Lw.res_b, Lw.ln_w,
-                               Lw.ln_b, Lw.fc1_b, Lw.fc2_b, h_out, n, p.Fn, p.Ft, p.Dkv, p.H, nullptr};
+                               Lw.ln_b, Lw.fc1_b, Lw.fc2_b, h_out, n, p.Fn, p.Ft, p.Dkv, p.H, nullptr,
+                               attn_in_post ? F32(p.qk) : nullptr, edge_feat, I32(p.eid[l]), F32(p.dt[l]), p.k, p.Fe, scale};
             if (const char* st_env = getenv("DYGNN_CHAIN_STAMPS")) po.stamps = reinterpret_cast<unsigned long long*>(strtoull(st_env, nullptr, 0));      // tools/chain_stamps.py
             if (int rc = chain::launch_post(s, po)) return rc;
             if (direct) return DYGNN_OK;

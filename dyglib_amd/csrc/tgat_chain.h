@@ -53,8 +53,11 @@ struct PreArgs {
 int launch_pre(hipStream_t s, const PreArgs& a);
 
 // rows i: att = W_v,h z_ih -> residual_fc + q_in -> LayerNorm -> [. | raw] -> relu(fc1) -> fc2 -> out[i][:]   (models/modules.py:186-199, :42-68)
+// With `qk` given (and post_fuses_attention()) the kernel also runs the attention over its rows' k neighbours itself (tgat_attn.h) and z never
+// leaves LDS; otherwise it reads z [n][H][Dkv] written by the attention kernel.
+bool post_fuses_attention(int64_t n, int Fn, int Ft, int Dkv, int H, int k);
 struct PostArgs {
-    const float* z;                // [n][H][Dkv]
+    const float* z;                // [n][H][Dkv] (NULL when the attention is fused)
     const float* h_lower;
     const float* node_feat;
     const int32_t* lower_ids;
@@ -68,6 +71,12 @@ struct PostArgs {
     int64_t n;
     int Fn, Ft, Dkv, H;
     unsigned long long* stamps;    // diagnostic: s_memtime of wave 0 at the stage boundaries, 16 per workgroup (NULL: off)
+    // fused attention (or qk = NULL): W_k^T q rows [n][H][Dkv], edge table, the level's neighbour edge ids / time differences [n][k]
+    const float *qk, *edge_feat;
+    const int32_t* nbr_eid;
+    const float* nbr_dt;
+    int k, Fe;
+    float scale;
 };
 int launch_post(hipStream_t s, const PostArgs& a);
 

@@ -15,6 +15,7 @@
 // fragment form (k_pack), zero-padded to whole tiles / chunks so no step needs a mask; LDS rows are zero-padded to the 16-k chunk.
 #include <cstdlib>
 #include "tgat_chain.h"
+#include "tgat_attn.h"
 
 namespace dygnn {
 namespace chain {
@@ -370,8 +371,8 @@ __global__ __launch_bounds__(kThreads) void k_tgat_pre(const PreArgs a) {
     });
 }
 
-struct PostLds { int ldz, ldq, ldm, ldh, r0, par, total; };
-__host__ __device__ inline PostLds post_layout(int R, int Fn, int Ft, int Dkv, int H) {
+struct PostLds { int ldz, ldq, ldm, ldh, r0, par, att, total; };
+__host__ __device__ inline PostLds post_layout(int R, int Fn, int Ft, int Dkv, int H, int KC = 0) {
     PostLds y;
     const int Dq = Fn + Ft;
     y.ldz = pad_ld((H - 1) * Dkv + r16(Dkv));
@@ -382,11 +383,12 @@ __host__ __device__ inline PostLds post_layout(int R, int Fn, int Ft, int Dkv, i
     y.r0 = a > b ? a : b;                       // region 0: z rows, later (z is dead after the W_v product) q_in rows | MergeLayer input rows
     const int r1 = R * (y.ldq > y.ldh ? y.ldq : y.ldh);      // region 1: att rows, later hid rows
     y.par = y.r0 + r1;                          // then the bias / LayerNorm vectors: res_b | ln_w | ln_b (3 Dq) | fc1_b | fc2_b (2 Fn)
-    y.total = y.par + 3 * Dq + 2 * Fn;
+    y.att = y.par + 3 * Dq + 2 * Fn;            // then the staging of the fused attention (tgat_attn.h), KC row slots per lane
+    y.total = y.att + (KC ? attn::pair_smem_floats(kWaves, H, KC, Ft) : 0);
     return y;
 }
 
-template <int MT>
+template <int MT, int KC>      // KC > 0: the attention over the rows' k <= KC neighbours runs here (z stays in LDS); 0: z comes from the attention kernel
 __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
     const int64_t nl = a.n_live ? (int64_t)*a.n_live : a.n;
     if (i0 >= nl) return;
     const int Fn = a.Fn, Ft = a.Ft, Dq = Fn + Ft, Dkv = a.Dkv, H = a.H, hd = Dq / H, Dm = Dq + Fn;
-    const PostLds L = post_layout(R, Fn, Ft, Dkv, H);
+    const PostLds L = post_layout(R, Fn, Ft, Dkv, H, KC);
     const int ldz = L.ldz, ldq = L.ldq, ldm = L.ldm, ldh = L.ldh;
     float* zb = lds;
     float* qin = lds;
@@ -421,7 +423,24 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
     rows.load(a.tw, a.tb, a.h_lower, a.node_feat, a.lower_ids, a.lower_map, i0, nl, Fn, Dq, wave, lane);
     for (int f = threadIdx.x; f < Dq; f += kThreads) { res_b[f] = a.res_b[f]; ln_w[f] = a.ln_w[f]; ln_b[f] = a.ln_b[f]; }
     for (int f = threadIdx.x; f < Fn; f += kThreads) { fc1_b[f] = a.fc1_b[f]; fc2_b[f] = a.fc2_b[f]; }
-    {   // z rows of the block (float4, coalesced); rows beyond the live count and the padding columns are zero
+    if constexpr (KC > 0) {
+        // z rows of the block computed here: two waves per row, four rows at a time (attn::pair_node has one workgroup barrier inside)
+        for (int rr = wave; rr < R; rr += kWaves) {
+            for (int f = H * Dkv + lane; f < ldz; f += 64) zb[rr * ldz + f] = 0.f;      // padding columns
+            for (int f = Dq + lane; f < ldq; f += 64) att[rr * ldq + f] = 0.f;
+        }
+#pragma unroll 1
+        for (int g4 = 0; g4 < MT; ++g4) {
+            const int row = 4 * g4 + (wave >> 1);
+            int64_t i = i0 + row;
+            const bool live = i < nl;
+            if (!live) i = nl - 1;              // a stand-in keeps the barrier uniform; the row's z is zeros
+            attn::pair_node<KC>(a.qk, a.h_lower, a.node_feat, a.edge_feat, a.lower_ids, a.nbr_eid, a.nbr_dt, a.tw, a.tb, a.n, a.k, Fn, a.Fe, Ft, H, a.scale, a.lower_map, i,
+                                live, true, wave, kWaves, lane, lds + L.att, zb + row * ldz, Dkv);
+            if (g4 + 1 < MT) __syncthreads();   // the staging is reused
+        }
+    } else {
+        // z rows of the block (float4, coalesced); rows beyond the live count and the padding columns are zero
         const int z4 = (H * Dkv) >> 2, l4 = ldz >> 2;
         for (int rr = wave; rr < R; rr += kWaves) {
             const int64_t i = i0 + rr;
@@ -618,7 +637,7 @@ __global__ __launch_bounds__(kThreads) void k_tgn_gru_chain(const GruArgs a) {
 }
 
 static size_t pre_lds(int Fn, int Ft, int H, int MT) { return (size_t)4 * MT * (pad_ld(Fn + Ft) + pad_ld((Fn + Ft) / H)) * sizeof(float); }
-static size_t post_lds(int Fn, int Ft, int Dkv, int H, int MT) { return (size_t)post_layout(4 * MT, Fn, Ft, Dkv, H).total * sizeof(float); }
+static size_t post_lds(int Fn, int Ft, int Dkv, int H, int MT, int KC = 0) { return (size_t)post_layout(4 * MT, Fn, Ft, Dkv, H, KC).total * sizeof(float); }
 static int gru_slices() {          // DYGNN_GRU_SLICES = 1 .. 6: tuning override (read per call)
     const char* e = getenv("DYGNN_GRU_SLICES");
     return (e && e[0] >= '1' && e[0] <= '6' && e[1] == 0) ? e[0] - '0' : kGruSlices;
@@ -666,20 +685,39 @@ int launch_pre(hipStream_t s, const PreArgs& a) {
     return MT == 8 ? launch_pre_mt<8>(s, a) : MT == 4 ? launch_pre_mt<4>(s, a) : MT == 2 ? launch_pre_mt<2>(s, a) : launch_pre_mt<1>(s, a);
 }
 
-template <int MT>
+template <int MT, int KC>
 static int launch_post_mt(hipStream_t s, const PostArgs& a) {
-    const size_t bytes = post_lds(a.Fn, a.Ft, a.Dkv, a.H, MT);
-    if (int rc = set_lds(k_tgat_post<MT>, bytes)) return rc;
-    hipLaunchKernelGGL(k_tgat_post<MT>, dim3((unsigned)ceil_div(a.n, 4 * MT)), dim3(kThreads), bytes, s, a);
+    const size_t bytes = post_lds(a.Fn, a.Ft, a.Dkv, a.H, MT, KC);
+    if (int rc = set_lds(k_tgat_post<MT, KC>, bytes)) return rc;
+    hipLaunchKernelGGL((k_tgat_post<MT, KC>), dim3((unsigned)ceil_div(a.n, 4 * MT)), dim3(kThreads), bytes, s, a);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;
 }
+static int post_mt(int64_t n, int Fn, int Ft, int Dkv, int H) {
+    int MT = env_mt("DYGNN_CHAIN_MT", pick_mt(n));
+    while (MT > 1 && post_lds(Fn, Ft, Dkv, H, MT) > kLdsMax) MT >>= 1;
+    return MT;
+}
+// the attention rides in k_tgat_post for small row blocks (4 or 8 rows: levels of up to a few thousand rows) whose neighbourhoods fit the
+// two-waves-per-node form; DYGNN_CHAIN_ATTN=0 keeps it a kernel of its own (A/B switch)
+static int fused_kc(int64_t n, int Fn, int Ft, int Dkv, int H, int k) {
+    const char* e = getenv("DYGNN_CHAIN_ATTN");
+    if (e && e[0] == '0') return 0;
+    const int MT = post_mt(n, Fn, Ft, Dkv, H);
+    if (MT > 2 || k > 20 || H > 2 || Dkv > 512) return 0;
+    const int KC = k <= 10 ? 10 : 20;
+    return post_lds(Fn, Ft, Dkv, H, MT, KC) <= kLdsMax ? KC : 0;
+}
+bool post_fuses_attention(int64_t n, int Fn, int Ft, int Dkv, int H, int k) { return fused_kc(n, Fn, Ft, Dkv, H, k) != 0; }
 int launch_post(hipStream_t s, const PostArgs& a) {
     if (a.n == 0) return DYGNN_OK;
     DYGNN_REQUIRE(fits(a.Fn, a.Ft, a.Dkv, a.H), "tgat chain: feature dims do not fit the row-block kernels");
-    int MT = env_mt("DYGNN_CHAIN_MT", pick_mt(a.n));
-    while (MT > 1 && post_lds(a.Fn, a.Ft, a.Dkv, a.H, MT) > kLdsMax) MT >>= 1;
-    return MT == 8 ? launch_post_mt<8>(s, a) : MT == 4 ? launch_post_mt<4>(s, a) : MT == 2 ? launch_post_mt<2>(s, a) : launch_post_mt<1>(s, a);
+    const int MT = post_mt(a.n, a.Fn, a.Ft, a.Dkv, a.H);
+    const int KC = a.qk ? fused_kc(a.n, a.Fn, a.Ft, a.Dkv, a.H, a.k) : 0;
+    DYGNN_REQUIRE(KC != 0 || a.z != nullptr, "tgat chain: neither z nor a fusable attention");
+    if (KC == 10) return MT == 2 ? launch_post_mt<2, 10>(s, a) : launch_post_mt<1, 10>(s, a);
+    if (KC == 20) return MT == 2 ? launch_post_mt<2, 20>(s, a) : launch_post_mt<1, 20>(s, a);
+    return MT == 8 ? launch_post_mt<8, 0>(s, a) : MT == 4 ? launch_post_mt<4, 0>(s, a) : MT == 2 ? launch_post_mt<2, 0>(s, a) : launch_post_mt<1, 0>(s, a);
 }
 
 template <int MT>
