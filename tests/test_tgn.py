@@ -126,18 +126,20 @@ def test_fused_step_equals_negative_then_positive_call():
 
 
 @pytest.mark.gpu
-def test_hip_mid_size_batches_against_oracle():
+@pytest.mark.parametrize("layers,K,NB", [(1, 10, 12), (2, 6, 5)])
+def test_hip_mid_size_batches_against_oracle(layers, K, NB):
     """BASELINE config 5's call shape on a mid-size graph: B = 200, k = 10, 1 layer, 12 chronological batches from interaction 0 with
     the memory carried across them (negative call, then positive call, per batch — through the one-call step), against
-    oracle/tgn_oracle.py: every batch's four embedding blocks, and the memory bank + last-update times left behind."""
+    oracle/tgn_oracle.py: every batch's four embedding blocks, and the memory bank + last-update times left behind.  And a two-layer model
+    (k = 6): the row-block chains over a de-duplicated level 1 (device-side row count, rows of the level below through the map)."""
     import torch
     from dyglib_amd import MemoryModel, get_neighbor_sampler
     from oracle import dygformer_oracle as orc
-    dev, B, K, NB = "cuda:0", 200, 10, 12
+    dev, B = "cuda:0", 200
     data, nf, ef = syn.make_bipartite_graph(700, 60, 40_000, seed=11, edge_feat_kind="sparse4", duplicate_time_every=13)
-    params = syn.make_tgn_params(5, nf.shape[0], num_layers=1)
+    params = syn.make_tgn_params(5, nf.shape[0], num_layers=layers)
     sampler = get_neighbor_sampler(data, "recent", seed=1, device=dev)
-    m = MemoryModel(nf, ef, sampler, 100, model_name="TGN", num_layers=1, num_heads=2, dropout=0.1, device=dev)
+    m = MemoryModel(nf, ef, sampler, 100, model_name="TGN", num_layers=layers, num_heads=2, dropout=0.1, device=dev)
     sd = m.state_dict(); sd.update({k: torch.from_numpy(v) for k, v in params.items()}); m.load_state_dict(sd)
     m = m.to(dev).eval()
     m.memory_bank.__init_memory_bank__()
@@ -152,12 +154,12 @@ def test_hip_mid_size_batches_against_oracle():
             s, d, t, e = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl], data.edge_ids[sl]
             ng = syn.random_negative_dst(rs, ud, B)
             ps, pd, ns, nd = m.compute_step_embeddings(s, d, s, ng, t, e, num_neighbors=K)
-            ons, ond = tn.tgn_forward(tp, nft, eft, adj, st, s, ng, t, None, False, 1, K, 2)
-            ops, opd = tn.tgn_forward(tp, nft, eft, adj, st, s, d, t, e, True, 1, K, 2)
+            ons, ond = tn.tgn_forward(tp, nft, eft, adj, st, s, ng, t, None, False, layers, K, 2)
+            ops, opd = tn.tgn_forward(tp, nft, eft, adj, st, s, d, t, e, True, layers, K, 2)
             for got, want, what in ((ps, ops, "pos src"), (pd, opd, "pos dst"), (ns, ons, "neg src"), (nd, ond, "neg dst")):
-                close(got.cpu().numpy(), want.numpy(), f"tgn mid-size batch {i} {what}", label=f"tgn mid-size (B=200, k=10, 12 batches) {what}")
-    close(m.memory_bank.node_memories.data.cpu().numpy(), st.M.numpy(), "tgn mid-size memory after 12 batches")
-    close(m.memory_bank.node_last_updated_times.data.cpu().numpy(), st.U.numpy(), "tgn mid-size last update after 12 batches")
+                close(got.cpu().numpy(), want.numpy(), f"tgn mid-size batch {i} {what}", label=f"tgn mid-size (B=200, k={K}, {layers} layer(s), {NB} batches) {what}")
+    close(m.memory_bank.node_memories.data.cpu().numpy(), st.M.numpy(), f"tgn mid-size memory after {NB} batches ({layers} layer(s))")
+    close(m.memory_bank.node_last_updated_times.data.cpu().numpy(), st.U.numpy(), f"tgn mid-size last update after {NB} batches ({layers} layer(s))")
 
 
 @pytest.mark.gpu
