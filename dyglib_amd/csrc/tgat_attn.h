@@ -96,21 +96,50 @@ __device__ __forceinline__ void pair_node(const float* __restrict__ qk, const fl
     }
 #pragma unroll
     for (int j = 0; j < KC; ++j)
-        if (j >= k) xs[j] = zero;
-    // (C) partial scores of this half, all (row, head) reductions pipelined
+        if (j >= k) xs[j] = zero;                           // idle row slots contribute exact zeros
+    // (C) partial scores of this half.  The KC sums over the 64 lanes are a reduce-scatter, not KC all-reduces: across lane bit 5 a lane
+    // keeps half of its values and sends the other half (one exchange adds TWO rows' partial sums), across bit 4 again, then the 16 lanes
+    // of a row of lanes finish the KC/4 values they are left with: 35 cross-lane exchanges for 20 rows instead of 120 (this kernel is
+    // bound by instruction issue, not by its gathers: profiles/r02_tgat_attn_notes.md).  The sums are formed in the same order for every
+    // node, whatever the batch.
+    constexpr int N1 = KC / 2, N2 = (N1 + 1) / 2;
+    static_assert(KC % 2 == 0, "KC must be even");
+    const bool up32 = (lane & 32) != 0, up16 = (lane & 16) != 0;      // where the folds below leave which rows
     auto dot4 = [](const af4 a, const af4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); };
     for (int h = 0; h < H; ++h) {
         const af4 q = vcol ? *reinterpret_cast<const af4*>(qk + ((size_t)i * H + h) * Dkv + kk) : zero;
-        float sc[KC];
+        // rows p, p + N2 (even / odd row of lanes) and p + N1, p + N1 + N2 (upper half) meet in one value per lane.  v_permlane32_swap(a, b)
+        // moves the upper half of a and the lower half of b into each other's place: a' + b' = (a summed across lane bit 5) in the lower
+        // lanes, (b summed) in the upper ones -- one swap and one add for two rows, no select, no LDS; v_permlane16_swap the same across bit 4.
+        float s2[N2];
+        auto fold32 = [](float a, float b) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+            const unsigned r0 = r[0], r1 = r[1];
+            return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+        };
+        auto fold16 = [](float a, float b) {
+            const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+            const unsigned r0 = r[0], r1 = r[1];
+            return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+        };
 #pragma unroll
-        for (int j = 0; j < KC; ++j) sc[j] = dot4(q, xs[j]);
+        for (int p = 0; p < N2; ++p) {
+            const bool two = p + N2 < N1;                   // (compile time: the odd one out when N1 is odd)
+            const float t0 = fold32(dot4(q, xs[p]), dot4(q, xs[p + N1]));
+            const float t1 = two ? fold32(dot4(q, xs[two ? p + N2 : p]), dot4(q, xs[two ? p + N1 + N2 : p])) : 0.f;
+            s2[p] = fold16(t0, t1);
+        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
+        for (int o = 8; o > 0; o >>= 1)
 #pragma unroll
-            for (int j = 0; j < KC; ++j) sc[j] += __shfl_xor(sc[j], o, 64);
+            for (int p = 0; p < N2; ++p) s2[p] += __shfl_xor(s2[p], o, 64);
+        if ((lane & 15) == 0) {                             // lane 16 r of row r = 2 (upper half) + (odd row) holds rows p + N2 * odd + N1 * upper
 #pragma unroll
-        for (int j = 0; j < KC; ++j)
-            if (lane == j) part[((slot * 2 + hf) * H + h) * KC + j] = sc[j];
+            for (int p = 0; p < N2; ++p) {
+                const int jh = p + (up16 ? N2 : 0);
+                if (jh < N1) part[((slot * 2 + hf) * H + h) * KC + jh + (up32 ? N1 : 0)] = s2[p];
+            }
+        }
     }
     __syncthreads();
     {   // softmax over the k neighbours: lane = 32 * head + row (modules.py:173 scale, :176-184 mask)
