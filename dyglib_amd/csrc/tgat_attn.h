@@ -129,10 +129,16 @@ __device__ __forceinline__ void pair_node(const float* __restrict__ qk, const fl
             const float t1 = two ? fold32(dot4(q, xs[two ? p + N2 : p]), dot4(q, xs[two ? p + N1 + N2 : p])) : 0.f;
             s2[p] = fold16(t0, t1);
         }
+        // ... and the 16 lanes of a row of lanes: rotations inside the row (DPP row_ror 8, 4, 2, 1: every lane ends with the sum), no LDS
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1)
-#pragma unroll
-            for (int p = 0; p < N2; ++p) s2[p] += __shfl_xor(s2[p], o, 64);
+        for (int p = 0; p < N2; ++p) {
+            float v = s2[p];
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+            s2[p] = v;
+        }
         if ((lane & 15) == 0) {                             // lane 16 r of row r = 2 (upper half) + (odd row) holds rows p + N2 * odd + N1 * upper
 #pragma unroll
             for (int p = 0; p < N2; ++p) {
