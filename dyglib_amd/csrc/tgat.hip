@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_tgat_attn_lin(const float* __restrict__
 }
 
 // The same attention with TWO waves per node (k <= KC, H <= 2, Dkv <= 512; tgat_attn.h: attn::pair_node).  Workgroup = 2 nodes.
-template <int KC>
+template <int KC, bool FULL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tgat_attn_pair(const float* __restrict__ qk, const float* __restrict__ h_lower, const float* __restrict__ node_feat,
                                                           const float* __restrict__ edge_feat, const int32_t* __restrict__ lower_ids,
                                                           const int32_t* __restrict__ nbr_eid, const float* __restrict__ nbr_dt, const float* __restrict__ tw,
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const bool live = i < nl;
     if (!live) i = nl - 1;                                  // keeps the barrier uniform; nothing is written
     const int Dkv = Fn + Fe + Ft;
-    attn::pair_node<KC>(qk, h_lower, node_feat, edge_feat, lower_ids, nbr_eid, nbr_dt, tw, tb, n, k, Fn, Fe, Ft, H, scale, lower_map, i, live, false, wave, 4, lane,
+    attn::pair_node<KC, FULL>(qk, h_lower, node_feat, edge_feat, lower_ids, nbr_eid, nbr_dt, tw, tb, n, k, Fn, Fe, Ft, H, scale, lower_map, i, live, false, wave, 4, lane,
                         reinterpret_cast<float*>(smem), z + (size_t)i * H * Dkv, Dkv);
 }
 
@@ -645,12 +645,13 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
             // idle slots re-read row 0), 20 otherwise.  Idle slots contribute exact zeros, so a row's bits do not depend on KC.
             const int KC = p.k <= 10 ? 10 : 20;
             const size_t lds2 = ((size_t)8 * p.H * KC + (size_t)4 * KC * TW) * sizeof(float);
-            if (KC == 10)
-                hipLaunchKernelGGL((k_tgat_attn_pair<10>), dim3((unsigned)ceil_div(n, 2)), dim3(256), lds2, s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]),
-                                   F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z), nl, lmap);
-            else
-            hipLaunchKernelGGL((k_tgat_attn_pair<20>), dim3((unsigned)ceil_div(n, 2)), dim3(256), lds2, s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]),
-                               F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z), nl, lmap);
+            // (k == KC: the instantiation without idle row slots; the bits of a row are the same)
+#define DYGNN_ATTN_LAUNCH(KC_, FULL_)                                                                                                                           \
+    hipLaunchKernelGGL((k_tgat_attn_pair<KC_, FULL_>), dim3((unsigned)ceil_div(n, 2)), dim3(256), lds2, s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), \
+                       I32(p.eid[l]), F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z), nl, lmap)
+            if (KC == 10) { if (p.k == 10) DYGNN_ATTN_LAUNCH(10, true); else DYGNN_ATTN_LAUNCH(10, false); }
+            else { if (p.k == 20) DYGNN_ATTN_LAUNCH(20, true); else DYGNN_ATTN_LAUNCH(20, false); }
+#undef DYGNN_ATTN_LAUNCH
         } else if (p.k <= 20)
             hipLaunchKernelGGL((k_tgat_attn_lin<20>), grid, dim3(256), lds + (size_t)4 * 20 * p.Ft * sizeof(float), s, F32(p.qk), h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]), F32(p.dt[l]),
                                w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, p.H, scale, F32(p.z));

@@ -45,7 +45,7 @@ __host__ __device__ inline int pair_smem_floats(int waves, int H, int KC, int Ft
 // waves run the same softmax on lanes (h, j); (D) weighted sum of the cached rows, stored at zrow + h * zhs (head stride): the node's z
 // [H][Dkv] in global memory or in LDS.  A dead slot (live = false: i is a stand-in) stores nothing, or zeros with zero_dead.
 // smem: pair_smem_floats(waves, ...) floats; wave = index of the calling wave among `waves`.
-template <int KC>
+template <int KC, bool FULL = false>      // FULL: k == KC, no idle row slots (their index clamps and zero fills drop out)
 __device__ __forceinline__ void pair_node(const float* __restrict__ qk, const float* __restrict__ h_lower, const float* __restrict__ node_feat,
                                           const float* __restrict__ edge_feat, const int32_t* __restrict__ lower_ids, const int32_t* __restrict__ nbr_eid,
                                           const float* __restrict__ nbr_dt, const float* __restrict__ tw, const float* __restrict__ tb, int64_t n, int k, int Fn,
@@ -78,7 +78,7 @@ __device__ __forceinline__ void pair_node(const float* __restrict__ qk, const fl
         const size_t st = cls == 0 ? (size_t)Fn : (size_t)Fe;
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
-            const int64_t r = r0 + (j < k ? j : 0);
+            const int64_t r = r0 + ((FULL || j < k) ? j : 0);
             const int64_t nrow = h_lower ? (lower_map ? (int64_t)lower_map[n + r] : n + r) : (int64_t)lower_ids[n + r];
             const int64_t erow = nbr_eid[r];
             xs[j] = *reinterpret_cast<const af4*>(bp + (cls == 0 ? nrow : erow) * st);
@@ -92,11 +92,13 @@ __device__ __forceinline__ void pair_node(const float* __restrict__ qk, const fl
     if (cls == 2) {
         const int lt = (col - T0) >> 1;
 #pragma unroll
-        for (int j = 0; j < KC; ++j) xs[j] = *reinterpret_cast<const af4*>(tf + (j < k ? j : 0) * TW + 4 * lt);
+        for (int j = 0; j < KC; ++j) xs[j] = *reinterpret_cast<const af4*>(tf + ((FULL || j < k) ? j : 0) * TW + 4 * lt);
     }
+    if constexpr (!FULL) {
 #pragma unroll
-    for (int j = 0; j < KC; ++j)
-        if (j >= k) xs[j] = zero;                           // idle row slots contribute exact zeros
+        for (int j = 0; j < KC; ++j)
+            if (j >= k) xs[j] = zero;                       // idle row slots contribute exact zeros
+    }
     // (C) partial scores of this half.  The KC sums over the 64 lanes are a reduce-scatter, not KC all-reduces: across lane bit 5 a lane
     // keeps half of its values and sends the other half (one exchange adds TWO rows' partial sums), across bit 4 again, then the 16 lanes
     // of a row of lanes finish the KC/4 values they are left with: 35 cross-lane exchanges for 20 rows instead of 120 (this kernel is
@@ -172,7 +174,7 @@ __device__ __forceinline__ void pair_node(const float* __restrict__ qk, const fl
         af4 za = zero;
 #pragma unroll
         for (int j = 0; j < KC; ++j) {                 // no early exit: a break keeps xs[] from being promoted to registers
-            const float p = j < k ? pw[h * KC + j] : 0.f;
+            const float p = (FULL || j < k) ? pw[h * KC + j] : 0.f;
             za.x = fmaf(p, xs[j].x, za.x); za.y = fmaf(p, xs[j].y, za.y); za.z = fmaf(p, xs[j].z, za.z); za.w = fmaf(p, xs[j].w, za.w);
         }
         if (vcol && (live || zero_dead)) *reinterpret_cast<af4*>(zrow + (size_t)h * zhs + kk) = live ? za : zero;

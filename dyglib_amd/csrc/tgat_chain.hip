@@ -228,9 +228,14 @@ struct WStream {
                 f4 r[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {          // k-slices 0 + 1, 2 + 3, then the pairs: fixed order
-                    f4 v = acc[m];
-                    v.x += __shfl_xor(v.x, 4, 64); v.y += __shfl_xor(v.y, 4, 64); v.z += __shfl_xor(v.z, 4, 64); v.w += __shfl_xor(v.w, 4, 64);
-                    v.x += __shfl_xor(v.x, 8, 64); v.y += __shfl_xor(v.y, 8, 64); v.z += __shfl_xor(v.z, 8, 64); v.w += __shfl_xor(v.w, 8, 64);
+                    f4 v = acc[m];                      // rotations inside the row of 16 lanes (DPP row_ror 4, then 8): no LDS
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = v[e];
+                        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));
+                        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));
+                        v[e] = x;
+                    }
                     r[m] = v;
                     acc[m] = zero;
                 }
@@ -435,8 +440,8 @@ __global__ __launch_bounds__(kThreads) void k_tgat_post(const PostArgs a) {
             int64_t i = i0 + row;
             const bool live = i < nl;
             if (!live) i = nl - 1;              // a stand-in keeps the barrier uniform; the row's z is zeros
-            attn::pair_node<KC>(a.qk, a.h_lower, a.node_feat, a.edge_feat, a.lower_ids, a.nbr_eid, a.nbr_dt, a.tw, a.tb, a.n, a.k, Fn, a.Fe, Ft, H, a.scale, a.lower_map, i,
-                                live, true, wave, kWaves, lane, lds + L.att, zb + row * ldz, Dkv);
+            attn::pair_node<KC, false>(a.qk, a.h_lower, a.node_feat, a.edge_feat, a.lower_ids, a.nbr_eid, a.nbr_dt, a.tw, a.tb, a.n, a.k, Fn, a.Fe, Ft, H, a.scale, a.lower_map,
+                                       i, live, true, wave, kWaves, lane, lds + L.att, zb + row * ldz, Dkv);
             if (g4 + 1 < MT) __syncthreads();   // the staging is reused
         }
     } else {
