@@ -86,38 +86,18 @@ __global__ __launch_bounds__(256) void k_tgat_expand(const int64_t* __restrict__
     }
 }
 
-// rows of the K/V input [n*k][Fn+Fe+Ft] = [h(neighbour) | edge feature | cos(w dt + b)] and of the query input
-// [n][Fn+Ft] = [h(self) | cos(b)]   (models/modules.py:150-157; the query's time feature is the encoding of dt = 0,
-// models/TGAT.py:84)
-__global__ __launch_bounds__(256) void k_tgat_inputs(const float* __restrict__ h_lower, const float* __restrict__ node_feat,
-                                                       const float* __restrict__ edge_feat, const int32_t* __restrict__ lower_ids,
-                                                       const int32_t* __restrict__ nbr_eid, const float* __restrict__ nbr_dt,
-                                                       const float* __restrict__ tw, const float* __restrict__ tb, int64_t n, int k, int Fn, int Fe,
-                                                       int Ft, float* __restrict__ kv_in, float* __restrict__ q_in, const int32_t* __restrict__ n_live,
-                                                       const int32_t* __restrict__ lower_map) {
-    // row r in [0, n*k): neighbour (i = r / k, j = r % k) = lower-level entry n + r ; rows n*k .. n*k+n-1: the query rows
-    const int64_t r = kv_in ? (int64_t)blockIdx.x : n * k + blockIdx.x;      // kv_in == NULL: query rows only
-    if (n_live && !kv_in && (int64_t)blockIdx.x >= *n_live) return;
-    const int Kkv = Fn + Fe + Ft, Kq = Fn + Ft;
-    if (r < n * k) {
-        const int64_t le = n + r;
-        const float* hsrc = h_lower ? h_lower + le * Fn : node_feat + (size_t)lower_ids[le] * Fn;   // layer 1: raw features
-        const float* esrc = edge_feat + (size_t)nbr_eid[r] * Fe;
-        const float dt = nbr_dt[r];
-        float* o = kv_in + r * Kkv;
-        for (int f = threadIdx.x; f < Kkv; f += blockDim.x) {
-            float v;
-            if (f < Fn) v = hsrc[f];
-            else if (f < Fn + Fe) v = esrc[f - Fn];
-            else v = cosf(fmaf(dt, tw[f - Fn - Fe], tb[f - Fn - Fe]));
-            o[f] = v;
-        }
-    } else {
-        const int64_t i = r - n * k;
-        const float* hsrc = h_lower ? h_lower + (lower_map ? (int64_t)lower_map[i] : i) * Fn : node_feat + (size_t)lower_ids[i] * Fn;
-        float* o = q_in + i * Kq;
-        for (int f = threadIdx.x; f < Kq; f += blockDim.x) o[f] = f < Fn ? hsrc[f] : cosf(fmaf(0.0f, tw[f - Fn], tb[f - Fn]));
-    }
+// the query-input rows alone, [n][Fn+Ft] = [h(self) | cos(b)]: one wave per row, four rows per workgroup, float4 copies (its predecessor, one
+// 256-thread workgroup per 1.1-KB row, ran a 119 k-row level at 1.3 TB/s: 163 us) (models/modules.py:150-157)
+__global__ __launch_bounds__(256) void k_tgat_qrows(const float* __restrict__ h_lower, const float* __restrict__ node_feat, const int32_t* __restrict__ lower_ids,
+                                                      const float* __restrict__ tw, const float* __restrict__ tb, int64_t n, int Fn, int Ft,
+                                                      float* __restrict__ q_in, const int32_t* __restrict__ n_live, const int32_t* __restrict__ lower_map) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n || (n_live && i >= *n_live)) return;
+    const float* hsrc = h_lower ? h_lower + (lower_map ? (int64_t)lower_map[i] : i) * Fn : node_feat + (size_t)lower_ids[i] * Fn;
+    float* o = q_in + i * (Fn + Ft);
+    for (int x = lane; x < (Fn >> 2); x += kWave) *reinterpret_cast<f4*>(o + 4 * x) = *reinterpret_cast<const f4*>(hsrc + 4 * x);
+    for (int f = lane; f < Ft; f += kWave) o[Fn + f] = cosf(fmaf(0.0f, tw[f], tb[f]));      // the encoding of dt = 0 (models/TGAT.py:84)
 }
 
 using attn::cos_time_t;
@@ -416,8 +396,16 @@ __global__ void k_dedup_insert(const int32_t* __restrict__ ids, const double* __
 __global__ void k_dedup_number(const int32_t* __restrict__ ids, const double* __restrict__ times, const int32_t* __restrict__ canon, int64_t n,
                                int32_t* __restrict__ count, int32_t* __restrict__ cidx, int32_t* __restrict__ cids, double* __restrict__ ctimes) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || canon[i] != (int32_t)i) return;
-    const int32_t c = atomicAdd(count, 1);
+    const bool rep = i < n && canon[i] == (int32_t)i;
+    // one atomic per wave reserves the compact indices of its representatives (one per representative: 10^5 same-address atomics, 54 us)
+    const uint64_t m = __ballot(rep);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    int32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, leader, 64);
+    if (!rep) return;
+    const int32_t c = base + __popcll(m & ((1ull << lane) - 1));
     cidx[i] = c;
     cids[c] = ids[i];
     ctimes[c] = times[i];
@@ -627,8 +615,8 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
                               p.Fn, p.Ft, p.Dkv, p.H};
             if (int rc = chain::launch_pre(s, pa)) return rc;
         } else {
-        hipLaunchKernelGGL(k_tgat_inputs, dim3((unsigned)n), dim3(256), 0, s, h_lower, node_feat, edge_feat, I32(p.ids[l - 1]), I32(p.eid[l]),
-                           F32(p.dt[l]), w->time_w, w->time_b, n, p.k, p.Fn, p.Fe, p.Ft, (float*)nullptr, F32(p.q_in), nl, lmap);     // query rows
+        hipLaunchKernelGGL(k_tgat_qrows, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, s, h_lower, node_feat, I32(p.ids[l - 1]), w->time_w, w->time_b, n, p.Fn, p.Ft,
+                           F32(p.q_in), nl, lmap);     // query rows
         DYGNN_LAUNCH_CHECK();
         if (int rc = gemm_nt<false>(F32(p.q_in), Lw.query_w, nullptr, F32(p.q), n, p.Dq, p.Dq, p.Dq, s, nl)) return rc;
         // qk[i][h] = W_k,h^T q_ih : per head [n][hd] x [hd][Dkv] (rows h*hd .. of key_w), one batched launch over the heads
