@@ -1,5 +1,5 @@
 // Row-block chains of the TGAT / TGN layer (tgat_chain.hip): the dependent small products of a layer run inside ONE workgroup that owns
-// 16 or 32 rows, activations in LDS, weights streamed from L2 straight into MFMA operands, so a layer is three launches
+// 4 .. 32 rows, activations in LDS, weights streamed from the cache hierarchy straight into MFMA operands, so a layer is three launches
 // (k_tgat_pre -> attention -> k_tgat_post) instead of nine and its intermediates (q_in, q, att, fc, merge_in, hid) never reach HBM.
 #pragma once
 #include "common.h"

@@ -2,7 +2,7 @@
 //
 // One workgroup (8 wave64) owns R = 4*MT rows of a level (R = 4 .. 32, chosen from the level size so that small levels still spread over
 // the chip).  Every product of the chain is Out[R][N] = Act[R][K] . W^T with the activations in LDS and the weight operand streamed from
-// the packed buffer (L2-resident: a layer is 2 MB) straight into the MFMA A operand of `v_mfma_f32_4x4x1_16b_f32`: sixteen independent
+// the packed buffer (a layer is 2 MB: Infinity Cache / L2 traffic, re-streamed by every workgroup) straight into the MFMA A operand of `v_mfma_f32_4x4x1_16b_f32`: sixteen independent
 // 4x4 outer products per instruction, used as 4 groups of n (4 outputs each) x 4 slices of k against FOUR rows -- full matrix-core rate
 // at four rows per workgroup, where a 16x16x4 tile would need sixteen (the first version of these kernels used 16-row tiles: a TGN
 // step's 800 roots were 50 workgroups on 256 CUs, each bound by its own CU's matrix pipe and L1; profiles/r02_tgn_chain_notes.md).
