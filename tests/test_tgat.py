@@ -187,3 +187,29 @@ def test_hip_level_deduplication_changes_nothing(monkeypatch):
     t1 = np.concatenate([rt, nt.reshape(-1).astype(np.float64)])
     distinct = len(set(zip(ids1.tolist(), t1.view(np.int64).tolist())))
     assert total == 2 * len(src) * 22 and computed == 2 * len(src) + distinct and computed < total // 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["gemm", "chains"])
+def test_hip_other_feature_dims_against_oracle(form, monkeypatch):
+    """feature dims that are not multiples of the 16-wide tiles / chunks of either layer form (node 40, edge 24, time 24 -> query dim 64, head dim 32,
+    key / value input 88) and k = 7 (idle row slots in the attention): both forms against the oracle"""
+    from dyglib_amd import TGAT, get_neighbor_sampler
+    data, nf, ef = syn.make_bipartite_graph(300, 50, 12000, seed=41, edge_feat_dim=24)
+    nf = np.ascontiguousarray(nf[:, :40])
+    nf[1:] = np.random.RandomState(8).standard_normal(nf[1:].shape).astype(np.float32) * 0.5
+    params = syn.make_tgat_params(12, node_feat_dim=40, edge_feat_dim=24, time_feat_dim=24, num_layers=2)
+    sampler = get_neighbor_sampler(data, "recent", seed=1, device="cuda:0")
+    m = TGAT(nf, ef, sampler, 24, num_layers=2, num_heads=2, dropout=0.1, device="cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    m = m.to("cuda:0").eval()
+    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    idx = np.concatenate([np.arange(3), np.arange(data.num_interactions - 150, data.num_interactions)])      # incl. nodes without history
+    src, dst, t = data.src_node_ids[idx], data.dst_node_ids[idx], data.node_interact_times[idx]
+    os_, od = torc.tgat_forward(params, nf, ef, adj, src, dst, t, 2, 7, 2)
+    if form == "chains":
+        monkeypatch.setenv("DYGNN_TGAT_CHAIN", "1")
+    with torch.no_grad():
+        gs, gd = m.compute_src_dst_node_temporal_embeddings(src, dst, t, num_neighbors=7)
+    close(gs.cpu().numpy(), os_.numpy(), f"other dims ({form}) src")
+    close(gd.cpu().numpy(), od.numpy(), f"other dims ({form}) dst")
