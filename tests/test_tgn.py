@@ -231,3 +231,48 @@ def test_rows_and_state_do_not_depend_on_the_workgroup_shapes(monkeypatch):
     gemm = run({"DYGNN_TGAT_CHAIN": "0"})
     close(base[0].cpu().numpy(), gemm[0].cpu().numpy(), "tgn chain vs GEMM form: rows")
     close(base[1].cpu().numpy(), gemm[1].cpu().numpy(), "tgn chain vs GEMM form: memory")
+
+
+@pytest.mark.gpu
+def test_hip_other_feature_dims_against_oracle():
+    """feature dims that are not multiples of the 16-wide tiles / chunks of the row-block kernels (node = memory 40, edge 24, time 24: message
+    128, GRU gates 120 = 7.5 tiles split over the slices), two layers, k = 7: sequential batches against the oracle incl. the memory bank"""
+    import torch
+    from dyglib_amd import MemoryModel, get_neighbor_sampler
+    from oracle import dygformer_oracle as orc
+    dev, B, K, NB, Fn, Fe, Ft, layers = "cuda:0", 120, 7, 6, 40, 24, 24, 2
+    data, nf, ef = syn.make_bipartite_graph(300, 40, 12_000, seed=43, edge_feat_dim=Fe, duplicate_time_every=11)
+    nf = np.ascontiguousarray(nf[:, :Fn])
+    nf[1:] = np.random.RandomState(9).standard_normal(nf[1:].shape).astype(np.float32) * 0.5
+    rs = np.random.RandomState(21)
+    tg = syn.make_tgat_params(13, node_feat_dim=Fn, edge_feat_dim=Fe, time_feat_dim=Ft, num_layers=layers)
+    params = {("embedding_module." + k if not k.startswith("time_encoder") else k): v for k, v in tg.items()}
+    for k in ("time_encoder.w.weight", "time_encoder.w.bias"):
+        params["embedding_module." + k] = params[k]
+    Dm, b = 2 * Fn + Ft + Fe, 1.0 / np.sqrt(Fn)
+    params["memory_updater.memory_updater.weight_ih"] = rs.uniform(-b, b, (3 * Fn, Dm)).astype(np.float32)
+    params["memory_updater.memory_updater.weight_hh"] = rs.uniform(-b, b, (3 * Fn, Fn)).astype(np.float32)
+    params["memory_updater.memory_updater.bias_ih"] = rs.uniform(-b, b, (3 * Fn,)).astype(np.float32)
+    params["memory_updater.memory_updater.bias_hh"] = rs.uniform(-b, b, (3 * Fn,)).astype(np.float32)
+    sampler = get_neighbor_sampler(data, "recent", seed=1, device=dev)
+    m = MemoryModel(nf, ef, sampler, Ft, model_name="TGN", num_layers=layers, num_heads=2, dropout=0.1, device=dev)
+    sd = m.state_dict(); sd.update({k: torch.from_numpy(v) for k, v in params.items()}); m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    m.memory_bank.__init_memory_bank__()
+    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    nft, eft = torch.from_numpy(nf), torch.from_numpy(ef)
+    tp = {k: torch.from_numpy(v) for k, v in params.items()}
+    st = tn.TgnState(nf.shape[0], Fn)
+    ud = np.unique(data.dst_node_ids)
+    with torch.no_grad():
+        for i in range(NB):
+            sl = slice(i * B, (i + 1) * B)
+            s, d, t, e = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl], data.edge_ids[sl]
+            ng = syn.random_negative_dst(rs, ud, B)
+            ps, pd, ns, nd = m.compute_step_embeddings(s, d, s, ng, t, e, num_neighbors=K)
+            ons, ond = tn.tgn_forward(tp, nft, eft, adj, st, s, ng, t, None, False, layers, K, 2)
+            ops, opd = tn.tgn_forward(tp, nft, eft, adj, st, s, d, t, e, True, layers, K, 2)
+            for got, want, what in ((ps, ops, "pos src"), (pd, opd, "pos dst"), (ns, ons, "neg src"), (nd, ond, "neg dst")):
+                close(got.cpu().numpy(), want.numpy(), f"tgn other dims batch {i} {what}", label=f"tgn other dims {what}")
+    close(m.memory_bank.node_memories.data.cpu().numpy(), st.M.numpy(), "tgn other dims memory")
+    close(m.memory_bank.node_last_updated_times.data.cpu().numpy(), st.U.numpy(), "tgn other dims last update")
