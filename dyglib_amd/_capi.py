@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported first: see module docstring)
 from . import _build
 
 DYGNN_MAX_LAYERS = 8
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -116,6 +116,8 @@ SIGNATURES = {
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dygnn_tgat_forward": (C.c_int, [C.POINTER(TgatConfig), C.POINTER(TgatWeights), C.POINTER(Csr), C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dygnn_tgat_forward_roots": (C.c_int, [C.POINTER(TgatConfig), C.POINTER(TgatWeights), C.POINTER(Csr), C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dygnn_tgn_workspace_bytes": (C.c_size_t, [C.POINTER(TgatConfig), C.c_int64, C.c_int64]),
     "dygnn_tgn_forward": (C.c_int, [C.POINTER(TgatConfig), C.POINTER(TgatWeights), C.POINTER(GruWeights), C.POINTER(Csr), C.c_void_p, C.c_void_p,
                                     C.POINTER(TgnState), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,

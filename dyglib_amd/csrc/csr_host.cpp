@@ -31,7 +31,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" const char* dygnn_last_error(void) { return dygnn::g_last_error.c_str(); }
 
-extern "C" int dygnn_abi_version(void) { return 12; }
+extern "C" int dygnn_abi_version(void) { return 13; }
 
 extern "C" int dygnn_csr_build_host(int64_t num_edges, const int64_t* src, const int64_t* dst, const int64_t* eid,
                                     const double* ts, int64_t num_nodes, int64_t* indptr, int32_t* nbr_out,

@@ -55,14 +55,14 @@ __global__ __launch_bounds__(256) void k_tgat_expand(const int64_t* __restrict__
                                                        int32_t* __restrict__ lower_ids, double* __restrict__ lower_times,
                                                        int32_t* __restrict__ nbr_eid, float* __restrict__ nbr_dt, const int32_t* __restrict__ n_live,
                                                        const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const double* __restrict__ tq,
-                                                       int64_t B, const TgnTouch tt) {
+                                                       int64_t B, const TgnTouch tt, int per_root) {
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (tt.owner && blockIdx.x == 0 && threadIdx.x < 2) tt.counts[threadIdx.x] = 0;
     if (q >= n || (n_live && q >= *n_live)) return;      // n = layout size of the level, *n_live = entries in use (de-duplicated level)
     int64_t node = src ? (q < B ? src[q] : dst[q - B]) : (int64_t)ids[q];
     if (node < 0 || node >= num_nodes) node = 0;
-    const double t = src ? tq[q < B ? q : q - B] : times[q];
+    const double t = src ? tq[(per_root || q < B) ? q : q - B] : times[q];
     const int64_t lo = indptr[node], hi = indptr[node + 1];
     const int64_t i = wave_lower_bound3(cts, lo, hi, t, lane);
     const int64_t len = i - lo;
@@ -518,7 +518,7 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
                              const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
                              float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream,
                              const dygnn_tgat_levels* levels = nullptr, bool levels_in_workspace = false, bool expand_only = false,
-                             const TgnTouch* touch = nullptr, bool packed = false) {
+                             const TgnTouch* touch = nullptr, bool packed = false, bool times_per_root = false) {
     if (int rc = check_tgat(cfg)) return rc;
     DYGNN_REQUIRE(w && w->time_w && w->time_b, "tgat: null weights");
     DYGNN_REQUIRE(levels || (csr && csr->indptr && csr->num_nodes >= 1), "tgat: bad csr");
@@ -565,7 +565,7 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
         hipLaunchKernelGGL(k_tgat_expand, dim3((unsigned)ceil_div(p.n[l], 4)), dim3(256), 0, s, csr->indptr, csr->nbr, csr->eid, csr->ts, csr->num_nodes,
                            dd ? I32(p.dd_ids) : I32(p.ids[l]), dd ? F64(p.dd_times) : F64(p.times[l]), p.n[l], p.k, I32(p.ids[l - 1]), F64(p.times[l - 1]),
                            I32(p.eid[l]), F32(p.dt[l]), dd ? I32(p.dd_count) : (const int32_t*)nullptr, top ? src : nullptr, top ? dst : nullptr,
-                           top ? times : nullptr, batch, tch ? *touch : TgnTouch{});
+                           top ? times : nullptr, batch, tch ? *touch : TgnTouch{}, times_per_root ? 1 : 0);
         DYGNN_LAUNCH_CHECK();
         if (dedup && l == 2) {                    // level 1 is complete: find its distinct (node, time) entries
             const int64_t n1 = p.n[1];
@@ -784,6 +784,19 @@ extern "C" int dygnn_tgat_forward(const dygnn_tgat_config* cfg, const dygnn_tgat
                                   const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
                                   float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
     return tgat_forward_impl(cfg, w, csr, node_feat, edge_feat, src, dst, times, batch, out_src, out_dst, workspace, workspace_bytes, stream);
+}
+
+// Embeddings of a LIST of (node, time) roots [n_roots] (n_roots even: the roots are the level [first half ; second half] of n_roots / 2
+// "pairs", every root with its own time).  An evaluation step's positive and negative call share their source rows: the caller hands
+// [sources ; destinations ; negative destinations] over once instead of [sources ; destinations] + [sources ; negatives].
+extern "C" int dygnn_tgat_forward_roots(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_csr* csr, const float* node_feat,
+                                        const float* edge_feat, const int64_t* ids, const double* times, int64_t n_roots, float* out,
+                                        void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
+    DYGNN_REQUIRE(n_roots >= 0 && n_roots % 2 == 0, "tgat_forward_roots: n_roots must be even (pad with a repeated root)");
+    DYGNN_REQUIRE(n_roots == 0 || (ids && times && out && cfg), "tgat_forward_roots: null pointer");
+    const int64_t b = n_roots / 2;
+    return tgat_forward_impl(cfg, w, csr, node_feat, edge_feat, ids, ids + b, times, b, out, out + (size_t)b * (cfg ? cfg->node_feat_dim : 0), workspace, workspace_bytes,
+                             stream, nullptr, false, false, nullptr, false, true);
 }
 
 extern "C" size_t dygnn_tgn_workspace_bytes(const dygnn_tgat_config* cfg, int64_t num_nodes, int64_t batch) {

@@ -91,9 +91,11 @@ def evaluate_model_link_prediction(model_name: str, model: nn.Module, neighbor_s
         elif model_name == "TGAT" and neighbor_sampler.sample_neighbor_strategy == "recent":
             # rows do not depend on the batch they are in (fixed k, stateless sampling): the n batches are one call on n*B edges
             # positives and negatives in ONE call: level de-duplication (tgat.hip) then computes the shared source side once
-            cat = lambda c: np.concatenate([g[c] for g in groups_pos] + [g[c] for g in groups_neg])
-            emb = backbone.compute_src_dst_node_temporal_embeddings(cat(0), cat(1), cat(2), num_neighbors=num_neighbors)
-            prob = merge.link_probabilities(*emb).reshape(2, n, B)
+            # positives and negatives in ONE call on the roots [sources ; destinations ; negative destinations]: the negative call's sources are
+            # the positive call's (evaluate_models_utils.py:62-63), and level de-duplication (tgat.hip) computes every other repeated entry once
+            catp = lambda c: np.concatenate([g[c] for g in groups_pos])
+            se, de, ne = backbone.compute_step_embeddings(catp(0), catp(1), np.concatenate([g[1] for g in groups_neg]), catp(2), num_neighbors=num_neighbors)
+            prob = merge.link_probabilities(torch.cat([se, se]), torch.cat([de, ne])).reshape(2, n, B)
         elif model_name == "TGAT":      # random strategies consume the sampler's RandomState call by call: keep the reference's call order
             probs = []
             for gp, gn in zip(groups_pos, groups_neg):

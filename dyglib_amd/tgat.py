@@ -94,15 +94,7 @@ class TGAT(nn.Module):
         out_src, out_dst = out[0], out[1]
         if B == 0:
             return out_src, out_dst
-        cfg = _capi.TgatConfig(self.node_feat_dim, self.edge_feat_dim, self.time_feat_dim, self.num_layers, self.num_heads, int(num_neighbors))
-        w = _capi.TgatWeights()
-        w.time_w, w.time_b = self.time_encoder.w.weight.data_ptr(), self.time_encoder.w.bias.data_ptr()
-        for l in range(self.num_layers):
-            a, m, L = self.temporal_conv_layers[l], self.merge_layers[l], w.layers[l]
-            L.query_w, L.key_w, L.value_w = a.query_projection.weight.data_ptr(), a.key_projection.weight.data_ptr(), a.value_projection.weight.data_ptr()
-            L.ln_w, L.ln_b = a.layer_norm.weight.data_ptr(), a.layer_norm.bias.data_ptr()
-            L.res_w, L.res_b = a.residual_fc.weight.data_ptr(), a.residual_fc.bias.data_ptr()
-            L.fc1_w, L.fc1_b, L.fc2_w, L.fc2_b = m.fc1.weight.data_ptr(), m.fc1.bias.data_ptr(), m.fc2.weight.data_ptr(), m.fc2.bias.data_ptr()
+        cfg, w = self._config_and_weights(num_neighbors)
         nbytes = self._lib.dygnn_tgat_workspace_bytes(C.byref(cfg), B)
         if nbytes == 0:
             _capi.check(-1)                      # AssertionError with the library's message (e.g. num_neighbors <= 0)
@@ -125,6 +117,70 @@ class TGAT(nn.Module):
                                                  src.data_ptr(), dst.data_ptr(), tms.data_ptr(), B, out_src.data_ptr(), out_dst.data_ptr(),
                                                  ws.data_ptr(), ws.numel(), _capi.current_stream_ptr()))
         return out_src, out_dst
+
+    def compute_step_embeddings(self, src_node_ids, dst_node_ids, neg_dst_node_ids, node_interact_times, num_neighbors: int = 20):
+        """The positive and the negative call of an evaluation step (evaluate_models_utils.py:126-136) as ONE library call on the roots
+        [sources ; destinations ; negative destinations] at the batch times (dygnn_tgat_forward_roots): the negative call's sources are the
+        positive call's (:62-63) and a root's row does not depend on the batch it is in, so (src_emb, dst_emb, neg_dst_emb) are bit-identical to
+        compute_src_dst_node_temporal_embeddings(src, dst, t) and (src, neg_dst, t)[1].  `recent` sampling only (the random strategies consume the
+        sampler's RandomState call by call)."""
+        if self.neighbor_sampler.sample_neighbor_strategy != "recent":
+            raise NotImplementedError("compute_step_embeddings: `recent` sampling only; issue the two calls of the reference for the random strategies")
+        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("TGAT forward with autograd recording (training) is not built on the HIP path (SURVEY.md §8f-1): "
+                                      "call it under torch.no_grad()")
+        dev = self.merge_layers[0].fc1.weight.device
+        if dev.type != "cuda":
+            raise _capi.DygnnError("dyglib_amd.TGAT runs on an MI355X only; there is no CPU fallback")
+        if self.node_raw_features.device != dev:
+            self.node_raw_features = self.node_raw_features.to(dev)
+            self.edge_raw_features = self.edge_raw_features.to(dev)
+        csr = self.neighbor_sampler.csr
+        if getattr(self, "_validated_csr", None) is not csr:
+            csr.check_tables(self.node_raw_features.shape[0], self.edge_raw_features.shape[0])
+            self._validated_csr = csr
+        parts_i, parts_t = [], []
+        for ids in (src_node_ids, dst_node_ids, neg_dst_node_ids):
+            csr.check_query_ids(ids, limit=self.node_raw_features.shape[0])
+            parts_i.append(ids.to(device=dev, dtype=torch.int64) if isinstance(ids, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).to(dev))
+        tms = (node_interact_times.to(device=dev, dtype=torch.float64) if isinstance(node_interact_times, torch.Tensor)
+               else torch.from_numpy(np.ascontiguousarray(node_interact_times, dtype=np.float64)).to(dev))
+        B = parts_i[0].numel()
+        assert parts_i[1].numel() == B and parts_i[2].numel() == B and tms.numel() == B
+        pad = (3 * B) % 2                                   # the library takes an even number of roots: repeat the last one
+        roots = torch.cat(parts_i + ([parts_i[2][-1:]] if pad and B else []))
+        times = torch.cat([tms, tms, tms] + ([tms[-1:]] if pad and B else []))
+        n = roots.numel()
+        out = torch.empty((n, self.node_feat_dim), dtype=torch.float32, device=dev)
+        if B == 0:
+            return out[:0], out[:0], out[:0]
+        cfg, w = self._config_and_weights(num_neighbors)
+        nbytes = self._lib.dygnn_tgat_workspace_bytes(C.byref(cfg), n // 2)
+        if nbytes == 0:
+            _capi.check(-1)
+        key = (n // 2, int(num_neighbors), torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._workspace.get(key)
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            if len(self._workspace) > 8:
+                self._workspace.clear()
+            ws = self._workspace[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._last_call = (cfg, n // 2, ws)
+        _capi.check(self._lib.dygnn_tgat_forward_roots(C.byref(cfg), C.byref(w), csr.on_device(dev), self.node_raw_features.data_ptr(),
+                                                       self.edge_raw_features.data_ptr(), roots.data_ptr(), times.data_ptr(), n, out.data_ptr(),
+                                                       ws.data_ptr(), ws.numel(), _capi.current_stream_ptr()))
+        return out[:B], out[B:2 * B], out[2 * B:3 * B]
+
+    def _config_and_weights(self, num_neighbors: int):
+        cfg = _capi.TgatConfig(self.node_feat_dim, self.edge_feat_dim, self.time_feat_dim, self.num_layers, self.num_heads, int(num_neighbors))
+        w = _capi.TgatWeights()
+        w.time_w, w.time_b = self.time_encoder.w.weight.data_ptr(), self.time_encoder.w.bias.data_ptr()
+        for l in range(self.num_layers):
+            a, m, L = self.temporal_conv_layers[l], self.merge_layers[l], w.layers[l]
+            L.query_w, L.key_w, L.value_w = a.query_projection.weight.data_ptr(), a.key_projection.weight.data_ptr(), a.value_projection.weight.data_ptr()
+            L.ln_w, L.ln_b = a.layer_norm.weight.data_ptr(), a.layer_norm.bias.data_ptr()
+            L.res_w, L.res_b = a.residual_fc.weight.data_ptr(), a.residual_fc.bias.data_ptr()
+            L.fc1_w, L.fc1_b, L.fc2_w, L.fc2_b = m.fc1.weight.data_ptr(), m.fc1.bias.data_ptr(), m.fc2.weight.data_ptr(), m.fc2.bias.data_ptr()
+        return cfg, w
 
     def compute_node_temporal_embeddings(self, node_ids, node_interact_times, current_layer_num: int, num_neighbors: int = 20) -> torch.Tensor:
         """models/TGAT.py:66-136: the embedding of `node_ids` at `node_interact_times` after `current_layer_num` layers ([n, node_feat_dim]).

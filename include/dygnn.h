@@ -231,6 +231,15 @@ int dygnn_tgat_forward(const dygnn_tgat_config* cfg_host, const dygnn_tgat_weigh
                        const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
                        float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
 
+/* The same forward for a LIST of (node, time) roots: out [n_roots][node_feat_dim] = TGAT.compute_node_temporal_embeddings(ids, times,
+ * num_layers) (models/TGAT.py:66-136), every root with its own time (`recent` sampling).  n_roots must be even; workspace as for
+ * dygnn_tgat_forward with batch = n_roots / 2.  The evaluation step of evaluate_models_utils.py:126-136 needs the embeddings of
+ * [sources ; destinations ; negative destinations] at the batch times: its negative call repeats the sources of its positive call
+ * (:62-63), so one call on 3 B roots replaces two calls on 2 B roots each. */
+int dygnn_tgat_forward_roots(const dygnn_tgat_config* cfg_host, const dygnn_tgat_weights* w_host, const dygnn_csr* csr_host,
+                             const float* node_feat, const float* edge_feat, const int64_t* ids, const double* times, int64_t n_roots,
+                             float* out, void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
+
 /* The same forward on PRE-SAMPLED neighbours, for the random strategies (uniform / time_interval_aware, e.g. the reference's
  * best TGAT configuration on Reddit, utils/load_configs.py:83-84): the draws must come from the sampler's numpy RandomState
  * in the reference's recursion order (models/TGAT.py:92-110), so the host builds the level sets and this entry point runs

@@ -213,3 +213,26 @@ def test_hip_other_feature_dims_against_oracle(form, monkeypatch):
         gs, gd = m.compute_src_dst_node_temporal_embeddings(src, dst, t, num_neighbors=7)
     close(gs.cpu().numpy(), os_.numpy(), f"other dims ({form}) src")
     close(gd.cpu().numpy(), od.numpy(), f"other dims ({form}) dst")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [200, 37])
+def test_hip_step_embeddings_equal_the_two_calls(B):
+    """TGAT.compute_step_embeddings (dygnn_tgat_forward_roots: [sources ; destinations ; negative destinations] as one call, every root with
+    its own time; an odd number of roots is padded) returns the rows of the positive call and of the negative call bit for bit"""
+    from dyglib_amd import TGAT, get_neighbor_sampler
+    data, nf, ef = syn.make_bipartite_graph(500, 60, 30000, seed=31)
+    nf[1:] = np.random.RandomState(5).standard_normal(nf[1:].shape).astype(np.float32) * 0.5
+    sampler = get_neighbor_sampler(data, "recent", seed=1, device="cuda:0")
+    m = TGAT(nf, ef, sampler, 100, num_layers=2, num_heads=2, dropout=0.1, device="cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_tgat_params(9).items()})
+    m = m.to("cuda:0").eval()
+    idx = np.arange(data.num_interactions - B, data.num_interactions)
+    src, dst, t = data.src_node_ids[idx], data.dst_node_ids[idx], data.node_interact_times[idx]
+    neg = syn.random_negative_dst(np.random.RandomState(3), np.unique(data.dst_node_ids), B)
+    with torch.no_grad():
+        ps, pd = m.compute_src_dst_node_temporal_embeddings(src, dst, t, num_neighbors=20)
+        ns, nd = m.compute_src_dst_node_temporal_embeddings(src, neg, t, num_neighbors=20)
+        se, de, ne = m.compute_step_embeddings(src, dst, neg, t, num_neighbors=20)
+    assert torch.equal(ps, ns)                                          # the negative call's source rows ARE the positive call's
+    assert torch.equal(se, ps) and torch.equal(de, pd) and torch.equal(ne, nd)
