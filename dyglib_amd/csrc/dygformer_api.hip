@@ -118,17 +118,19 @@ __global__ __launch_bounds__(256) void k_merge_sigmoid_mfma(const float* __restr
 // multiplies it with cat(a, b)[row j][16 chunk + 4 ks ..] out of LDS.  400 rows = 100 workgroups; a wave's stream is 22 steps.
 // (The previous form, 16 rows per workgroup with 4 waves over the hidden units, took 16 us for 400 rows on 25 workgroups: every wave's
 // float4 operand loads touched 16 rows, and 4 or 8 k-steps in flight made no difference.)
+template <int MT>      // 4 MT rows per workgroup: 4 for an evaluation step's few hundred rows, 16 for thousands (the fc1 stream is shared by more rows)
 __global__ __launch_bounds__(1024) void k_merge_sigmoid_rows4(const float* __restrict__ a, const float* __restrict__ b, int64_t n_rows, int dim,
                                                                int hidden, const float* __restrict__ w1, const float* __restrict__ b1,
                                                                const float* __restrict__ w2, const float* __restrict__ b2,
                                                                float* __restrict__ out, int sig, int ldx) {
     extern __shared__ __attribute__((aligned(16))) float mlds[];
-    float* x = mlds;                      // [4][ldx] cat(a, b) rows, zero-padded to the 16-k chunk
-    float* zp = x + 4 * ldx;              // [waves][4] per-tile parts of the fc2 dot product
+    constexpr int R = 4 * MT;
+    float* x = mlds;                      // [R][ldx] cat(a, b) rows, zero-padded to the 16-k chunk
+    float* zp = x + R * ldx;              // [waves][R] per-tile parts of the fc2 dot product
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int j = lane & 3, ks = (lane >> 2) & 3, ng = lane >> 4;
     const int K = 2 * dim, nch = (K + 15) >> 4;
-    const int64_t r0 = (int64_t)blockIdx.x * 4;
+    const int64_t r0 = (int64_t)blockIdx.x * R;
     const int n_lane = 16 * wave + 4 * ng + j;
     const bool rowok = n_lane < hidden;
     const float* wp = w1 + (size_t)(rowok ? n_lane : 0) * K + 4 * ks;
@@ -136,12 +138,14 @@ __global__ __launch_bounds__(1024) void k_merge_sigmoid_rows4(const float* __res
     mf4 ring[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) ring[u] = *reinterpret_cast<const mf4*>(wp + ((16 * u + 4 * ks < K) ? 16 * u : 0));
-    for (int rr = wave; rr < 4; rr += nwaves) {
+    for (int rr = wave; rr < R; rr += nwaves) {
         const int64_t m = r0 + rr;
         for (int f = lane; f < ldx; f += 64) x[rr * ldx + f] = (m < n_rows && f < K) ? (f < dim ? a[m * dim + f] : b[m * dim + (f - dim)]) : 0.f;
     }
     __syncthreads();
-    mf4 acc = mf4{0.f, 0.f, 0.f, 0.f};
+    mf4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = mf4{0.f, 0.f, 0.f, 0.f};
     const float* xb = x + j * ldx + 4 * ks;
     for (int c0 = 0; c0 < nch; c0 += PF) {
 #pragma unroll
@@ -150,35 +154,41 @@ __global__ __launch_bounds__(1024) void k_merge_sigmoid_rows4(const float* __res
             if (ch < nch) {
                 const bool kok = 16 * ch + 4 * ks < K;
                 const mf4 w = (rowok && kok) ? ring[u] : mf4{0.f, 0.f, 0.f, 0.f};
-                const mf4 xv = *reinterpret_cast<const mf4*>(xb + 16 * ch);
                 const int nx = ch + PF;
                 ring[u] = *reinterpret_cast<const mf4*>(wp + ((nx < nch && 16 * nx + 4 * ks < K) ? 16 * nx : 0));
-                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, xv.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, xv.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, xv.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, xv.w, acc, 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const mf4 xv = *reinterpret_cast<const mf4*>(xb + m * 4 * ldx + 16 * ch);
+                    acc[m] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, xv.x, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, xv.y, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, xv.z, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, xv.w, acc[m], 0, 0, 0);
+                }
             }
         }
     }
     // k-slices 0 + 1, 2 + 3, then the pairs; then relu(h + b1) . w2 over the lane's four hidden units, the four groups, the tiles
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        acc[e] += __shfl_xor(acc[e], 4, 64);
-        acc[e] += __shfl_xor(acc[e], 8, 64);
-    }
-    float z = 0.f;
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int n = 16 * wave + 4 * ng + e;
-        if (n < hidden) z = fmaf(fmaxf(acc[e] + b1[n], 0.f), w2[n], z);
+        for (int e = 0; e < 4; ++e) {
+            acc[m][e] += __shfl_xor(acc[m][e], 4, 64);
+            acc[m][e] += __shfl_xor(acc[m][e], 8, 64);
+        }
+        float z = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = 16 * wave + 4 * ng + e;
+            if (n < hidden) z = fmaf(fmaxf(acc[m][e] + b1[n], 0.f), w2[n], z);
+        }
+        z += __shfl_xor(z, 16, 64);
+        z += __shfl_xor(z, 32, 64);
+        if (lane < 4) zp[wave * R + 4 * m + lane] = z;      // ng = 0, ks = 0, row 4 m + lane
     }
-    z += __shfl_xor(z, 16, 64);
-    z += __shfl_xor(z, 32, 64);
-    if (lane < 4) zp[wave * 4 + lane] = z;      // ng = 0, ks = 0, row j = lane
     __syncthreads();
-    if (threadIdx.x < 4 && r0 + threadIdx.x < n_rows) {
+    if (threadIdx.x < R && r0 + threadIdx.x < n_rows) {
         float t = 0.f;
-        for (int w = 0; w < nwaves; ++w) t += zp[w * 4 + threadIdx.x];
+        for (int w = 0; w < nwaves; ++w) t += zp[w * R + threadIdx.x];
         t += b2[0];
         out[r0 + threadIdx.x] = sig ? 1.0f / (1.0f + expf(-t)) : t;
     }
@@ -407,18 +417,23 @@ static int merge_forward(const float* a, const float* b, int64_t n, int32_t dim,
     DYGNN_REQUIRE(n >= 0 && dim > 0 && hidden > 0, "merge_layer: bad sizes");
     DYGNN_REQUIRE(n == 0 || (a && b && fc1_w && fc1_b && fc2_w && fc2_b && out), "merge_layer: null pointer");
     if (n == 0) return DYGNN_OK;
-    if (dim % 4 == 0 && n >= 2048) {        // few rows: the one-workgroup-per-row kernel below has the shorter critical path
-        hipLaunchKernelGGL(k_merge_sigmoid_mfma, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, as_stream(stream), a, b, n, dim, hidden,
-                           fc1_w, fc1_b, fc2_w, fc2_b, out, sig);
+    if (dim % 4 == 0 && hidden <= 256 && n >= 64) {     // an evaluation step's worth of rows (4 per workgroup) or thousands of them (16 per workgroup)
+        const int tiles = (hidden + 15) / 16, k16 = (2 * dim + 15) & ~15, ldx = (k16 & 16) ? k16 : k16 + 16;      // row stride % 32 == 16: the four rows on distinct banks
+        const int R = n >= 2048 ? 16 : 4;
+        const size_t lds4 = ((size_t)R * ldx + (size_t)R * tiles) * sizeof(float);
+        DYGNN_REQUIRE(lds4 <= 64 * 1024, "merge_layer: dim too large");
+        if (R == 16)
+            hipLaunchKernelGGL(k_merge_sigmoid_rows4<4>, dim3((unsigned)ceil_div(n, 16)), dim3(64 * tiles), lds4, as_stream(stream), a, b, n, dim, hidden,
+                               fc1_w, fc1_b, fc2_w, fc2_b, out, sig, ldx);
+        else
+            hipLaunchKernelGGL(k_merge_sigmoid_rows4<1>, dim3((unsigned)ceil_div(n, 4)), dim3(64 * tiles), lds4, as_stream(stream), a, b, n, dim, hidden,
+                               fc1_w, fc1_b, fc2_w, fc2_b, out, sig, ldx);
         DYGNN_LAUNCH_CHECK();
         return DYGNN_OK;
     }
-    if (dim % 4 == 0 && hidden <= 256 && n >= 64) {     // an evaluation step's worth of rows
-        const int tiles = (hidden + 15) / 16, k16 = (2 * dim + 15) & ~15, ldx = (k16 & 16) ? k16 : k16 + 16;      // row stride % 32 == 16: the four rows on distinct banks
-        const size_t lds4 = ((size_t)4 * ldx + 4 * tiles) * sizeof(float);
-        DYGNN_REQUIRE(lds4 <= 64 * 1024, "merge_layer: dim too large");
-        hipLaunchKernelGGL(k_merge_sigmoid_rows4, dim3((unsigned)ceil_div(n, 4)), dim3(64 * tiles), lds4, as_stream(stream), a, b, n, dim, hidden,
-                           fc1_w, fc1_b, fc2_w, fc2_b, out, sig, ldx);
+    if (dim % 4 == 0 && n >= 2048) {        // (hidden > 256) the wave-per-16-rows form
+        hipLaunchKernelGGL(k_merge_sigmoid_mfma, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, as_stream(stream), a, b, n, dim, hidden,
+                           fc1_w, fc1_b, fc2_w, fc2_b, out, sig);
         DYGNN_LAUNCH_CHECK();
         return DYGNN_OK;
     }

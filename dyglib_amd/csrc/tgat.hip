@@ -397,15 +397,22 @@ __global__ void k_dedup_number(const int32_t* __restrict__ ids, const double* __
                                int32_t* __restrict__ count, int32_t* __restrict__ cidx, int32_t* __restrict__ cids, double* __restrict__ ctimes) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool rep = i < n && canon[i] == (int32_t)i;
-    // one atomic per wave reserves the compact indices of its representatives (one per representative: 10^5 same-address atomics, 54 us)
+    // ONE atomic per 1024-thread workgroup reserves the compact indices of its representatives: lanes count inside their wave (ballot), waves
+    // inside the workgroup (LDS).  Same-address device atomics cost ~8 ns each here: one per representative was 54 us for 10^5 of them, one
+    // per wave still 51 us.
+    __shared__ int32_t s_cnt, s_base;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
     const uint64_t m = __ballot(rep);
-    if (!m) return;
-    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-    int32_t base = 0;
-    if (lane == leader) base = atomicAdd(count, __popcll(m));
-    base = __shfl(base, leader, 64);
+    int32_t off = 0;
+    if (lane == 0 && m) off = atomicAdd(&s_cnt, __popcll(m));
+    off = __shfl(off, 0, 64);
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(count, s_cnt) : 0;
+    __syncthreads();
     if (!rep) return;
-    const int32_t c = base + __popcll(m & ((1ull << lane) - 1));
+    const int32_t c = s_base + off + __popcll(m & ((1ull << lane) - 1));
     cidx[i] = c;
     cids[c] = ids[i];
     ctimes[c] = times[i];
@@ -574,7 +581,7 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
             hipLaunchKernelGGL(k_dedup_insert, dim3((unsigned)ceil_div(n1, 256)), dim3(256), 0, s, I32(p.ids[1]), F64(p.times[1]), n1, I32(p.dd_slots), p.dd_cap - 1,
                                I32(p.dd_canon));
             DYGNN_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_dedup_number, dim3((unsigned)ceil_div(n1, 256)), dim3(256), 0, s, I32(p.ids[1]), F64(p.times[1]), I32(p.dd_canon), n1, I32(p.dd_count),
+            hipLaunchKernelGGL(k_dedup_number, dim3((unsigned)ceil_div(n1, 1024)), dim3(1024), 0, s, I32(p.ids[1]), F64(p.times[1]), I32(p.dd_canon), n1, I32(p.dd_count),
                                I32(p.dd_cidx), I32(p.dd_ids), F64(p.dd_times));
             DYGNN_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_dedup_map, dim3((unsigned)ceil_div(n1, 256)), dim3(256), 0, s, I32(p.dd_canon), I32(p.dd_cidx), n1, I32(p.dd_map));
