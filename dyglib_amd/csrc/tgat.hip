@@ -349,20 +349,39 @@ __global__ __launch_bounds__(256) void k_tgat_post(const float* __restrict__ fc_
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n || (n_live && i >= *n_live)) return;
+    // the row lives in registers (Dq <= 272: five elements per lane) between the three passes; a lane adds its elements in the order of the
+    // three-loop form this replaces, so the bits are the same
+    constexpr int NV = 5;
+    float x[NV];
+    const float* raw = node_feat + (size_t)lower_ids[i] * Fn;
+    float rv[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int f = lane + kWave * u;
+        x[u] = f < Dq ? fc_out[i * Dq + f] + q_in[i * Dq + f] : 0.f;
+        rv[u] = f < Fn ? raw[f] : 0.f;
+    }
     float s = 0.f;
-    for (int f = lane; f < Dq; f += kWave) s += fc_out[i * Dq + f] + q_in[i * Dq + f];
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+        if (lane + kWave * u < Dq) s += x[u];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     const float mean = s / (float)Dq;
     float v = 0.f;
-    for (int f = lane; f < Dq; f += kWave) { const float d = fc_out[i * Dq + f] + q_in[i * Dq + f] - mean; v = fmaf(d, d, v); }
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+        if (lane + kWave * u < Dq) { const float d = x[u] - mean; v = fmaf(d, d, v); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     const float rstd = 1.0f / sqrtf(v / (float)Dq + 1e-5f);
     float* o = merge_in + i * (Dq + Fn);
-    for (int f = lane; f < Dq; f += kWave) o[f] = (fc_out[i * Dq + f] + q_in[i * Dq + f] - mean) * rstd * gamma[f] + beta[f];
-    const float* raw = node_feat + (size_t)lower_ids[i] * Fn;
-    for (int f = lane; f < Fn; f += kWave) o[Dq + f] = raw[f];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int f = lane + kWave * u;
+        if (f < Dq) o[f] = (x[u] - mean) * rstd * gamma[f] + beta[f];
+        if (f < Fn) o[Dq + f] = rv[u];
+    }
 }
 
 // ---- de-duplication of a level (recent sampling only) --------------------------------------------------------------------
