@@ -74,25 +74,70 @@ def _timed_cpu(step_fn, first: int, max_steps: int, budget_s: float, warm: int =
     for i in range(warm):
         step_fn(first + i)
     outs, n, t0 = [], 0, time.perf_counter()
+    STEP_TIMES.clear()
     while n < max_steps:
+        t1 = time.perf_counter()
         outs.append(step_fn(first + warm + n))
+        STEP_TIMES.append(time.perf_counter() - t1)
         n += 1
         if time.perf_counter() - t0 >= budget_s:
             break
     return n, time.perf_counter() - t0, outs
 
 
+STEP_TIMES: list = []          # per-step seconds of the last _timed_cpu sample (for the median)
+
+
 # ======================================================================================================================
 # DyGFormer workloads (headline: wikipedia; secondary: lastfm)
 # ======================================================================================================================
+def build_graph_once_per_node(name: str, share=None):
+    """The synthetic graph + feature tables of a workload.  With N > 1 ranks on one node (`share` = (dist, local_rank, tag)) local rank 0
+    generates them once and the other ranks map its arrays from /dev/shm (copy-on-write, nothing is written back) instead of
+    repeating the host work N times on one box; rank 0 removes the files once every rank has them mapped."""
+    wl = WORKLOADS[name]
+    gen = lambda: syn.make_bipartite_graph(wl["users"], wl["items"], wl["edges"], seed=0, edge_feat_kind=wl["edge_feat_kind"])
+    if share is None:
+        return gen()
+    import shutil
+    dist, local_rank, tag = share
+    d = os.path.join("/dev/shm", f"dygnn_bench_{tag}_{name}")
+    fields = ("src_node_ids", "dst_node_ids", "node_interact_times", "edge_ids", "labels")
+    out, err = None, None
+    if local_rank == 0:
+        try:
+            shutil.rmtree(d, ignore_errors=True)
+            os.makedirs(d)
+            data, nf, ef = out = gen()
+            for f in fields:
+                np.save(os.path.join(d, f + ".npy"), getattr(data, f))
+            np.save(os.path.join(d, "node_feat.npy"), nf)
+            np.save(os.path.join(d, "edge_feat.npy"), ef)
+        except Exception as e:          # the other ranks must not hang in the barrier: they fall back to generating on their own
+            err = e
+            shutil.rmtree(d, ignore_errors=True)
+    dist.barrier()
+    if local_rank != 0:
+        try:
+            ld = lambda f: np.load(os.path.join(d, f + ".npy"), mmap_mode="c")
+            out = (syn.InteractionData(*(ld(f) for f in fields)), ld("node_feat"), ld("edge_feat"))
+        except Exception:
+            out = gen()
+    dist.barrier()
+    if local_rank == 0:
+        shutil.rmtree(d, ignore_errors=True)
+        if err is not None:
+            raise err
+    return out
+
+
 class DygformerWorkload:
-    def __init__(self, name: str, dev, impl: int = 0):
+    def __init__(self, name: str, dev, impl: int = 0, share=None):
         from dyglib_amd import DyGFormer, MergeLayer, get_neighbor_sampler
         wl = WORKLOADS[name]
         self.name, self.wl, self.dev = name, wl, dev
         self.B, self.L, self.P = wl["batch"], wl["L"], wl["P"]
-        self.data, self.node_feat, self.edge_feat = syn.make_bipartite_graph(wl["users"], wl["items"], wl["edges"], seed=0,
-                                                                             edge_feat_kind=wl["edge_feat_kind"])
+        self.data, self.node_feat, self.edge_feat = build_graph_once_per_node(name, share)
         self.params = syn.make_dygformer_params(0, patch_size=self.P)
         self.mparams = syn.make_merge_layer_params(1000)
         self.sampler = get_neighbor_sampler(self.data, "recent", seed=1, device=dev)              # full graph, as in evaluation
@@ -164,8 +209,7 @@ def run_dygformer(wk: DygformerWorkload, steps: int, warmup: int, F: int, rank: 
             _, auc, _, _ = link_prediction_metrics_device(predicts, labels_full[:nsteps])
             m = torch.stack([auc.sum(), (pos.mean(dim=1) - negp.mean(dim=1)).double().sum(),
                              torch.full((), float(nsteps), dtype=torch.float64, device=dev)])
-            D.reduce_metric_sums(m)                              # RCCL all-reduce of 3 float64 when N > 1
-            metric_accs[li % len(streams)].add_(m)
+            metric_accs[li % len(streams)].add_(m)               # per-rank sums; ONE all-reduce after the timed region (SURVEY §8e needs only the totals)
             if keep_out:
                 kept.append((s, d, prob))
 
@@ -203,10 +247,17 @@ def run_dygformer(wk: DygformerWorkload, steps: int, warmup: int, F: int, rank: 
     run_steps(warmup, steps, events, keep_steps=keep)
     sync_all()
     elapsed = time.perf_counter() - t0
+    acc_dev = metric_accs[0] if len(metric_accs) == 1 else torch.stack(metric_accs).sum(dim=0)
+    reduce_ms = None
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # the evaluation's only exchange: [sum AUC, sum gap, #steps] of every rank, float64, summed over RCCL — once, outside the timed loop
+        t_r = time.perf_counter()
+        dist.all_reduce(acc_dev, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize(dev)
+        reduce_ms = (time.perf_counter() - t_r) * 1e3
     # dominant kernel = the fused forward, one launch per F steps: mean duration of the FULL launches, from HIP events recorded on the
     # launch stream inside the timed region right around that kernel's launch (the generic path: around the whole call)
     sizes = [min(F, steps - i * F) for i in range(n_launch)]
@@ -214,9 +265,10 @@ def run_dygformer(wk: DygformerWorkload, steps: int, warmup: int, F: int, rank: 
     impl_fused = wk.model.impl in (0, 3)
     call_ms = float(np.mean([events[i][0].elapsed_time(events[i][1]) for i in full]))           # window search + fused forward + host gaps
     launch_ms = float(np.mean([events[i][2].elapsed_time(events[i][3]) for i in full])) if impl_fused else call_ms
-    acc = sum(a.cpu().numpy() for a in metric_accs)
+    acc = acc_dev.cpu().numpy()
     return dict(elapsed=elapsed, value=steps * B * world / elapsed, launch_ms=launch_ms, call_ms=call_ms, steps_per_launch=sizes[0], n_launch=n_launch,
-                timed_launches=len(full), mean_auc=float(acc[0] / max(acc[2], 1)), kept=kept, order=order_h[warmup:warmup + steps], streams=len(streams))
+                timed_launches=len(full), mean_auc=float(acc[0] / max(acc[2], 1)), metric_steps=int(round(acc[2])), metric_allreduce_ms=reduce_ms,
+                kept=kept, order=order_h[warmup:warmup + steps], streams=len(streams))
 
 
 def dygformer_roofline(wk: DygformerWorkload, res: dict, impl: int) -> dict:
@@ -247,7 +299,7 @@ def dygformer_roofline(wk: DygformerWorkload, res: dict, impl: int) -> dict:
 
 
 # ---- CPU baseline + parity of the headline workload ---------------------------------------------------------------------------
-def cpu_baseline_and_parity(wk: DygformerWorkload, res: dict, budget_s: float, max_steps: int):
+def cpu_baseline_and_parity(wk: DygformerWorkload, res: dict, budget_s: float, max_steps: int, one_thread_s: float = 0.0):
     """The CPU oracle (restatement of the reference path, kind 'port') timed on this host on a bounded sample of the SAME
     workload — the first timed steps of the GPU run — and, from the same replay, the GPU/oracle parity of those steps."""
     from oracle import dygformer_oracle as orc
@@ -257,23 +309,34 @@ def cpu_baseline_and_parity(wk: DygformerWorkload, res: dict, budget_s: float, m
     adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
     P, L = wk.P, wk.L
 
+    order = list(res["order"])
+    order += [b for b in range(wk.n_batches) if b not in set(order)][:max(0, max_steps - len(order))]     # CPU-only steps beyond the GPU's timed ones
+
     def step(k):                                     # k-th timed step of the GPU run (k = -1: warm-up on another batch)
-        src, dst, neg, t = wk.batches[res["order"][k] if k >= 0 else res["order"][-1]]
+        src, dst, neg, t = wk.batches[order[k] if k >= 0 else order[-1]]
         with torch.no_grad():
             s, d = orc.dygformer_forward(wk.params, wk.node_feat, wk.edge_feat, adj, src, dst, t, P, L)
             ns, nd = orc.dygformer_forward(wk.params, wk.node_feat, wk.edge_feat, adj, src, neg, t, P, L)
             pos = orc.merge_layer(wk.mparams, s, d).squeeze(-1).sigmoid()
             ng = orc.merge_layer(wk.mparams, ns, nd).squeeze(-1).sigmoid()
         return s, d, ns, nd, pos, ng
-    n, el, outs = _timed_cpu(step, -1, min(max_steps, len(res["order"])), budget_s, warm=1)
-    base = {"value": round(n * wk.B / el, 1), "unit": "edges/s", "cores": cores, "kind": "port",
-            "sample": f"{n} of the timed 200-edge steps ({el:.1f} s) after 1 warm-up step; oracle/dygformer_oracle.py "
-                      f"(numpy sampling + PyTorch-CPU fp32 dense ops, torch threads={cores})"}
+    n, el, outs = _timed_cpu(step, -1, min(max_steps, len(order)), budget_s, warm=1)
+    med = float(np.median(STEP_TIMES))
+    base = {"value": round(wk.B / med, 1), "unit": "edges/s", "cores": cores, "kind": "port", "statistic": "median step time",
+            "mean_value": round(n * wk.B / el, 1), "steps": n,
+            "sample": f"{n} 200-edge steps of the evaluation span ({el:.1f} s; the GPU's timed steps first) after 1 warm-up step; "
+                      f"oracle/dygformer_oracle.py (numpy sampling + PyTorch-CPU fp32 dense ops, torch threads={cores})"}
+    if one_thread_s > 0:                             # the same steps at one thread
+        torch.set_num_threads(1)
+        n1, el1, _ = _timed_cpu(step, -1, 8, one_thread_s, warm=1)
+        base["one_thread"] = {"value": round(wk.B / float(np.median(STEP_TIMES)), 1), "unit": "edges/s", "cores": 1, "steps": n1,
+                              "sample": f"{n1} of the same steps ({el1:.1f} s), median, torch threads=1"}
+        torch.set_num_threads(cores)
     # parity: GPU outputs kept from the timed launches, step k = element k % F of launch k // F
     F = res["steps_per_launch"]
     e_emb = e_prob = ref_emb = 0.0
     checked = 0
-    for k in range(n):
+    for k in range(min(n, len(res["order"]))):
         if k // F >= len(res["kept"]):
             break
         s, d, prob = res["kept"][k // F]
@@ -294,9 +357,10 @@ def cpu_baseline_and_parity(wk: DygformerWorkload, res: dict, budget_s: float, m
 # ======================================================================================================================
 # stages
 # ======================================================================================================================
-def sampler_stage(sampler, data, dev, n_queries: int = 400_000, k: int = 20, reps: int = 5) -> dict:
+def sampler_stage(sampler, data, dev, n_queries: int = 2_000_000, k: int = 20, reps: int = 3) -> dict:
     """get_historical_neighbors ('recent', k = 20) on random (endpoint, time) queries of the evaluation span: queries/s and the
-    algorithmic-byte rate against the 8 TB/s HBM peak (the reference: 149 k queries/s on the CPU).  Bytes per query by SURVEY §8d's
+    algorithmic-byte rate against the 8 TB/s HBM peak (the reference: 149 k queries/s on the CPU).  2 M queries = 1.5 GB of algorithmic
+    bytes per pass, six times the 256 MB Infinity Cache: the outputs stream to HBM.  Bytes per query by SURVEY §8d's
     formula on this library's CSR (16 B per entry: int32 id, int32 edge id, float64 time): 8*ceil(log2(deg+1)) binary-search probe
     bytes + 16*min(history, k) window bytes + 20*k output bytes (int64, int64, float32) + 16 query bytes."""
     E = data.num_interactions
@@ -364,6 +428,65 @@ def per_call_stage(wk: DygformerWorkload, n_batches: int = 60) -> dict:
                          "what": "dyglib_amd.evaluate_model_link_prediction(fuse_batches=1): one 200-edge step per launch, numpy inputs per batch, "
                                  "device metrics, one host synchronisation per evaluation",
                          "mean_auc": round(float(np.mean([m["roc_auc"] for m in metrics])), 4)}}
+
+
+def full_span_stage(wk: DygformerWorkload, oracle_batches: int = 6, oracle_all: bool = False) -> dict:
+    """The metric over the span it is defined on: ALL batches of the last 30 % of the interactions (236 full batches + the
+    43-edge tail = 237) through `evaluate_model_link_prediction` — the loop of evaluate_models_utils.py:49-152 with its seeded `random`
+    negative sampler, per-batch AP / AUC / BCE on the device, host arrays in, one synchronisation at the end — and the per-batch AP / AUC of
+    `oracle_batches` of them (first, last = the ragged tail, and evenly spaced ones; all 237 with --full-span-oracle) recomputed by the CPU
+    oracle on the same negative draws."""
+    import torch.nn as nn
+    from dyglib_amd import NegativeEdgeSampler, evaluate_model_link_prediction, get_idx_data_loader
+    data, B = wk.data, wk.B
+    idx = list(range(wk.first, data.num_interactions))
+    nb = (len(idx) + B - 1) // B
+    model = nn.Sequential(wk.model, wk.merge)
+    mk = lambda: (get_idx_data_loader(idx, batch_size=B, shuffle=False), NegativeEdgeSampler(data.src_node_ids, data.dst_node_ids, seed=0))
+    run = lambda: evaluate_model_link_prediction("DyGFormer", model, wk.sampler, *mk(), data, nn.BCELoss())
+    run()                                                    # warm-up pass (same shapes)
+    torch.cuda.synchronize(wk.dev)
+    t0 = time.perf_counter()
+    losses, metrics = run()
+    torch.cuda.synchronize(wk.dev)
+    el = time.perf_counter() - t0
+    out = {"value": round(len(idx) / el, 1), "unit": "edges/s", "batches": nb, "edges": len(idx), "seconds": round(el, 4),
+           "mean_average_precision": float(np.mean([m["average_precision"] for m in metrics])), "mean_roc_auc": float(np.mean([m["roc_auc"] for m in metrics])),
+           "mean_loss": float(np.mean(losses)),
+           "what": "dyglib_amd.evaluate_model_link_prediction over the whole evaluation span (evaluate_models_utils.py:49-152): numpy inputs per batch, "
+                   "32 batches per launch, device AP / AUC / BCE, one host synchronisation"}
+    if oracle_batches > 0 or oracle_all:
+        from oracle import dygformer_oracle as orc, metrics_oracle as mo
+        torch.set_num_threads(cpu_threads())
+        adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+        negs = NegativeEdgeSampler(data.src_node_ids, data.dst_node_ids, seed=0)
+        negs.reset_random_state()
+        pick = set(range(nb)) if oracle_all else set(np.unique(np.linspace(0, nb - 1, oracle_batches).round().astype(int)).tolist())
+        d_ap = d_auc = 0.0
+        o_ap, o_auc = [], []
+        t1 = time.perf_counter()
+        for b in range(nb):
+            sl = idx[b * B:(b + 1) * B]
+            _, neg = negs.sample(size=len(sl))               # every batch draws, picked or not: the stream stays the evaluation's
+            if b not in pick:
+                continue
+            src, dst, t = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]
+            with torch.no_grad():
+                pos, ng = orc.link_prediction_step(wk.params, wk.mparams, wk.node_feat, wk.edge_feat, adj, src, dst, neg, t, wk.P, wk.L)
+            y = np.concatenate([np.ones(len(sl)), np.zeros(len(sl))])
+            pr = np.concatenate([pos.numpy(), ng.numpy()])
+            o_ap.append(mo.average_precision(y, pr)), o_auc.append(mo.roc_auc(y, pr))
+            d_ap = max(d_ap, abs(o_ap[-1] - metrics[b]["average_precision"]))
+            d_auc = max(d_auc, abs(o_auc[-1] - metrics[b]["roc_auc"]))
+        out["oracle_check"] = {"batches": sorted(pick) if not oracle_all else f"all {nb}", "max_abs_ap_diff": d_ap, "max_abs_auc_diff": d_auc,
+                               "oracle_mean_ap_of_checked": float(np.mean(o_ap)), "oracle_mean_auc_of_checked": float(np.mean(o_auc)),
+                               "gpu_mean_ap_of_checked": float(np.mean([metrics[b]["average_precision"] for b in sorted(pick)])),
+                               "gpu_mean_auc_of_checked": float(np.mean([metrics[b]["roc_auc"] for b in sorted(pick)])),
+                               "seconds": round(time.perf_counter() - t1, 1),
+                               "ok": bool(d_ap <= 1e-3 and d_auc <= 1e-3),
+                               "against": "oracle/dygformer_oracle.py + oracle/metrics_oracle.py on the same batches and negative draws; AP / AUC are rank "
+                                          "statistics of 400 scores each within 1e-4 of the oracle's: a swap of two near-tied scores moves them by ~1/40000, bar 1e-3"}
+    return {"full_span": out}
 
 
 # ======================================================================================================================
@@ -704,8 +827,11 @@ def parse_args():
                     help="upper bound of the steps per launch: the positive and negative calls of F consecutive steps (2F independently "
                          "padded groups of `batch` pairs) form ONE grid; F = min(this, steps/2) so that at least two launches are timed")
     ap.add_argument("--prime-launches", type=int, default=8, help="untimed launches of the timed shape before the warm-up steps (clock / cache ramp)")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall budget of the headline CPU-baseline sample (0 = skip CPU legs and parity)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the headline CPU-baseline sample (0 = skip CPU legs and parity)")
     ap.add_argument("--secondary", default="lastfm,tgat,tgn,train", help="comma list of secondary workloads to run at N=1 ('' or 'none' = skip)")
+    ap.add_argument("--full-span-oracle", action="store_true", help="stages.full_span: recompute ALL 237 batches' AP / AUC with the CPU oracle (~1 min)")
+    ap.add_argument("--sharded-secondary", default="lastfm", choices=["lastfm", "tiny", "none"],
+                    help="N > 1: workload that is also run sharded over the N ranks and printed as secondary.<name> (BASELINE config 4 = lastfm)")
     ap.add_argument("--budget-seconds", type=float, default=105.0, help="wall budget of the whole run: secondary CPU samples shrink to fit")
     return ap.parse_args()
 
@@ -731,15 +857,21 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # DYGNN_BENCH_FORCE_DIST=1: the process group (and with it the barrier, the MAX-reduce of the timed region and the float64 metric
+    # all-reduce on device tensors) is set up at world size 1 too — RCCL's first contact on a one-GPU box (tests/test_bench_multirank_gpu.py)
+    force_dist = bool(os.environ.get("DYGNN_BENCH_FORCE_DIST")) and world == 1
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    # one node: the graph is generated once (local rank 0) and mapped by the other ranks
+    share = (dist, local_rank, f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}") if world > 1 else None
 
-    wk = DygformerWorkload(args.workload, dev, args.impl)
+    wk = DygformerWorkload(args.workload, dev, args.impl, share=share)
     B, L, P = wk.B, wk.L, wk.P
     F = max(1, min(args.fuse_steps, args.steps // 2 if args.steps >= 2 else 1))
     solo = rank == 0 and world == 1
@@ -759,13 +891,35 @@ def main():
         "roofline": dygformer_roofline(wk, res, args.impl),
         "mean_auc": round(res["mean_auc"], 4),
     }
+    if dist is not None:
+        # the one exchange of the sharded evaluation, after the timed region: every rank's [sum AUC, sum gap, #steps] summed over the backend
+        out["metric_allreduce"] = {"backend": "RCCL (nccl)" if backend == "nccl" else backend, "ms": round(res["metric_allreduce_ms"], 3),
+                                   "steps_counted": res["metric_steps"], "steps_expected": args.steps * world}
+        if res["metric_steps"] != args.steps * world:
+            raise SystemExit(f"metric all-reduce counted {res['metric_steps']} steps, expected {args.steps * world}")
     failed = False
+    if world > 1 and args.sharded_secondary != "none":
+        # BASELINE config 4 is defined at N GPUs: the LastFM-shaped workload (L=512, P=8) sharded exactly like the headline, every rank K' steps
+        del wk
+        torch.cuda.empty_cache()
+        wk2 = DygformerWorkload(args.sharded_secondary, dev, args.impl, share=share)
+        st2, wu2, F2 = 16, 8, 8
+        res2 = run_dygformer(wk2, st2, wu2, F2, rank, world, dist, 1, keep=0, prime=4)
+        out["secondary"] = {args.sharded_secondary: {
+            "metric": f"edges/sec (link-prediction fwd) DyGFormer {WORKLOAD_LABEL[args.sharded_secondary]}, {world} ranks, edge-batch shard",
+            "value": round(res2["value"], 1), "unit": "edges/s", "n_gpus": world, "steps": st2, "warmup": wu2, "scaling": "weak",
+            "ms_per_step": round(res2["elapsed"] / st2 * 1e3, 4), "steps_per_launch": res2["steps_per_launch"],
+            "config": {"workload": wk2.describe()}, "roofline": dygformer_roofline(wk2, res2, args.impl), "mean_auc": round(res2["mean_auc"], 4),
+            "metric_allreduce": {"ms": round(res2["metric_allreduce_ms"], 3), "steps_counted": res2["metric_steps"]}}}
+        del wk2
     if solo:
         out["stages"] = sampler_stage(wk.sampler, wk.data, dev)           # stage-level number for the neighbour lookup
         out["stages"].update(metrics_stage(dev))
         out["stages"].update(per_call_stage(wk))
+        out["stages"].update(full_span_stage(wk, oracle_batches=6 if args.cpu_seconds > 0 else 0, oracle_all=args.full_span_oracle))
+        failed |= not out["stages"]["full_span"].get("oracle_check", {"ok": True})["ok"]
         if args.cpu_seconds > 0:
-            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(wk, res, args.cpu_seconds, 64)
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(wk, res, args.cpu_seconds, 32, one_thread_s=0.4 * args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = round(res["value"] / out["cpu_baseline"]["value"], 1)
             failed |= not out["parity"]["ok"]
         res["kept"] = None

@@ -34,9 +34,6 @@
 #ifndef F3_KSKIP
 #define F3_KSKIP 1
 #endif
-#ifndef F3_DQ
-#define F3_DQ 8
-#endif
 
 namespace dygnn {
 namespace v3 {
@@ -142,8 +139,7 @@ __device__ __forceinline__ float row_sum16(float v) {
 // cos(2 pi u) evaluated by an even degree-12 minimax polynomial (|err| <= 6e-8 on the folded range); beyond 3e7 the product's rounding
 // error would exceed 1e-7 turns and libm is called instead (tests/test_dygformer_gpu.py::test_large_timestamps_take_the_libm_cosine_path).
 // erf for the exact GELU: Abramowitz & Stegun 7.1.26 (|err| <= 1.5e-7), branch-free.
-__device__ __forceinline__ float cos_time(float x) {
-    if (!(fabsf(x) <= 3.0e7f)) return cosf(x);
+__device__ __forceinline__ float cos_time_fast(float x) {      // |x| <= 3e7 (branch-free; cos_time checks)
     const float INV_HI = 0.15915493667125702f, INV_LO = 6.4206382432985265e-09f;
     const float p = x * INV_HI;
     const float e = fmaf(x, INV_HI, -p);
@@ -161,6 +157,34 @@ __device__ __forceinline__ float cos_time(float x) {
     r = fmaf(r, z, -19.739208802178716f);
     r = fmaf(r, z, 1.0f);
     return flip ? -r : r;
+}
+__device__ __forceinline__ float cos_time(float x) { return fabsf(x) <= 3.0e7f ? cos_time_fast(x) : cosf(x); }
+// the same operations on two arguments at once, written on 2-vectors so that hipcc emits packed fp32 instructions (v_pk_mul / v_pk_fma /
+// v_pk_add_f32: two results per issue slot; the time channel of the projection is bound by VALU issue, not by the matrix pipe)
+using f2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 cos_time_fast2(f2 x) {
+    const f2 INV_HI = {0.15915493667125702f, 0.15915493667125702f}, INV_LO = {6.4206382432985265e-09f, 6.4206382432985265e-09f};
+    const f2 p = x * INV_HI;
+    const f2 e = pk_fma(x, INV_HI, -p);
+    const f2 q = pk_fma(x, INV_LO, e);
+    const f2 rp = {rintf(p.x), rintf(p.y)};
+    const f2 t = (p - rp) + q;
+    f2 u = {fabsf(t.x), fabsf(t.y)};
+    const f2 one_u = f2{1.0f, 1.0f} - u;
+    u = f2{u.x > 0.5f ? one_u.x : u.x, u.y > 0.5f ? one_u.y : u.y};
+    const bool fx = u.x > 0.25f, fy = u.y > 0.25f;
+    const f2 half_u = f2{0.5f, 0.5f} - u;
+    const f2 v = {fx ? half_u.x : u.x, fy ? half_u.y : u.y};
+    const f2 z = v * v;
+    auto c2 = [](float c) { return f2{c, c}; };
+    f2 r = pk_fma(c2(7.903536371318467f), z, c2(-26.42625678337438f));
+    r = pk_fma(r, z, c2(60.24464137187666f));
+    r = pk_fma(r, z, c2(-85.45681720669373f));
+    r = pk_fma(r, z, c2(64.93939402266829f));
+    r = pk_fma(r, z, c2(-19.739208802178716f));
+    r = pk_fma(r, z, c2(1.0f));
+    return f2{fx ? -r.x : r.x, fy ? -r.y : r.y};
 }
 __device__ __forceinline__ float erf_as(float x) {
     const float ax = fabsf(x);
@@ -186,7 +210,7 @@ struct Args {
     const float* stream; int nstages;
     const float* projw;           // projection fragments in step order [node | time | edge | cooc chunks][4 tiles]
     int proj_frags;               // total projection fragments
-    int slab_chunks;              // k-chunks (steps) per LDS slab
+    int slab_chunks;              // k-chunk slots per LDS HALF (a multiple of 4; two halves)
     int scr_floats;               // LDS floats reserved for the window arrays (the slab follows)
     int slab_in_ring;             // long windows (e.g. L = 2048): the slab borrows the weight ring, whose stream then opens after the prologue
     const float* bias_x;          // [208] projection biases in model-dim order
@@ -204,6 +228,8 @@ struct Args {
     float qscale;
     train::TrainOut tr;           // training forward only (k_dygformer_fused3<.., true>): the dense activations the backward pass reads
 };
+
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};      // load / LDS-DMA source for rows that do not exist
 
 // ---- the shared weight stream ---------------------------------------------------------------------------------
 struct WStream {
@@ -494,15 +520,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_dygformer_fused3(c
     WStream ws;
     if (!a.slab_in_ring) ws.open(a.stream, kLdsRing, lane, wave, a.nstages, NW);
     const float* ringl = lds + kLdsRing + lane * 4;
+    // projection fragments: two LDS halves of `slab_chunks` k-chunk slots each (4 fragments per slot), refilled by LDS-DMA one half
+    // ahead of the consumer (half q of the slot sequence lives in buffer q & 1)
     const int slab_off = a.slab_in_ring ? kLdsRing : a.scr_floats;
     const float* slabl = lds + slab_off + lane * 4;
-    const int slab_frags = 4 * a.slab_chunks;
-    auto load_slab = [&](int k) {
-        const int f0 = k * slab_frags;
-        const int n = a.proj_frags - f0 < slab_frags ? a.proj_frags - f0 : slab_frags;
-        for (int f = wave; f < n; f += NW) dma_frag(a.projw + (size_t)(f0 + f) * kFrag + lane * 4, slab_off + f * kFrag);
+    const int hc = a.slab_chunks;
+    const int half_frags = 4 * hc;
+    auto load_half = [&](int q) {
+        const int f0 = q * half_frags;
+        const int n = a.proj_frags - f0 < half_frags ? a.proj_frags - f0 : half_frags;      // <= 0 beyond the last half
+        for (int f = wave; f < n; f += NW) dma_frag(a.projw + (size_t)(f0 + f) * kFrag + lane * 4, slab_off + ((q & 1) * half_frags + f) * kFrag);
     };
-    load_slab(0);
+    load_half(0);
+    load_half(1);
     float* tws = lds + kLdsMisc + kMiscFloats;      // time-encoder w | b
     for (int i = tid; i < 2 * a.Ft; i += NTHR) tws[i] = i < a.Ft ? a.time_w[i] : a.time_b[i - a.Ft];
 
@@ -577,152 +607,254 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_dygformer_fused3(c
         const bool tv = tok < T;
         const int pos0 = tv ? (tok < Ts ? tok * a.P : SsA + (tok - Ts) * a.P) : 0;
         const int P = a.P;
-        constexpr int DQ = F3_DQ;          // gathered chunks in flight per lane (measured: profiles/r02_fused3_ab.md)
-        // (pp, f) = patch position and feature of this lane's k; row = the table row of that position, re-read from
-        // LDS only when pp moves on (once per ~11 chunks), so the gather address never waits for an LDS round trip
-        struct Cursor { int pp, f, row; };
-        int sstep = 0, next_slab = 1;
-        bool work = active && !src_shared;       // this wave gathers / multiplies in the current channel (shared source tiles: co-occurrence only)
-        // fragments of the next step (all waves call this in lock-step); *fresh: a new slab was loaded for it
-        auto slab_step = [&](bool& fresh) -> const float* {
-            fresh = false;
-            if (sstep == a.slab_chunks) {
-                __syncthreads();                            // everyone is done with the slab
-                load_slab(next_slab++);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Round 3: the whole phase is written WITHOUT branches around loads.  hipcc counts the loads in flight (s_waitcnt vmcnt / lgkmcnt (N))
+        // only while every path through the code issues the same loads: with the earlier form — gathers skipped for absent rows, the
+        // fragments of a step read "if fresh", cursor rows re-read on a wrap — every step waited `vmcnt(1)` for a gather issued one step
+        // before (queue depth 8 on paper) and `lgkmcnt(3)` for the fragment reads of the NEXT step just issued: the matrix pipe ran at 50 %
+        // (profiles/r03_lastfm_phase.txt).  Now absent rows are read from a zero word, cursors advance by selects with the next position's
+        // row read one step ahead, and the step count of every loop body is a template parameter.
+        constexpr int GS = 4;              // steps per group = gathered operands in flight per lane
+        static_assert(GS == 4, "the counted wait below is written as vmcnt(4)");
+        using std::integral_constant;
+        // ---- slot walk.  The channels' k-chunks occupy consecutive slots of the fragment sequence, every channel padded to whole groups
+        // of GS slots (build_proj); a half holds hc (a multiple of GS) slots, so a group never straddles a half.
+        int pj_half = 0, pj_slot = 0, pj_next = 2, pj_young = 0;      // pj_young: gathers this wave issued since its last LDS-DMA
+        auto frag_ptr = [&]() -> const float* { return slabl + (size_t)((pj_half * hc + pj_slot) * 4) * kFrag; };
+        // A group is done (its last fragment read is issued).  At the end of a half: this wave's DMAs of the NEXT half have landed — they are
+        // older than its last GS gathers, vmcnt retires in issue order, so `vmcnt(GS)` proves it without waiting for the gathers in flight —
+        // its own reads of the finished half are complete, one barrier, and the finished half's buffer is refilled two halves ahead.
+        auto end_group = [&](bool counted) {
+            pj_slot += GS;
+            if (pj_slot == hc) {
+                if (counted && pj_young >= GS) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
                 __syncthreads();
-                sstep = 0;
-                fresh = true;
+                load_half(pj_next++);
+                pj_young = 0; pj_half ^= 1; pj_slot = 0;
             }
-            return slabl + (size_t)(sstep++) * 4 * kFrag;
         };
-        auto row_of = [&](const int32_t* idx, int pp) -> int {
-            if (!tv || pp >= P) return -1;
-            const int32_t r = idx[pos0 + pp];
-            return r < 0 ? 0 : r;
+        auto run_idle = [&](int n) { for (int i = 0; i < (n + GS - 1) / GS; ++i) end_group(false); };     // a wave without work in this channel keeps the barriers
+        // fragments of one step: 4 tiles
+        auto read_frags = [&](f4 (&dst)[4], const float* fr) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dst[v] = lds4(fr + v * kFrag);
         };
-        auto gather = [&](const float* table, int F, const Cursor& cu) -> f4 {
-            if (cu.row < 0) return zero4();
-            return ldg4(table + (size_t)cu.row * F + cu.f);                                          // DyGFormer.py:259-261
+        // fragment reads of step u of an NS-step group: the next step's, or — on the last step of a full group, after the half protocol —
+        // the first step's of the NEXT group into fa[0] (a channel's last group reads ahead in vain: the next channel starts FRESH)
+        auto frags_ahead = [&](auto NSc, int u, const float* fr, f4 (&fa)[2][4], bool counted) {
+            constexpr int NS = decltype(NSc)::value;
+            if (u + 1 < NS) read_frags(fa[(u + 1) & 1], fr + (size_t)(u + 1) * 4 * kFrag);
+            else {
+                end_group(counted);
+                if (NS == GS) read_frags(fa[0], frag_ptr());
+            }
         };
-        auto step_gather = [&](Cursor& cu, const int32_t* idx, int F) {
+
+        // ---- gathered channels (node, edge features): (pp, f) = patch position and feature of this lane's k, row = the table row of that
+        // position, rown = the row of position pp + 1 (read from LDS one step ahead, every step: no branch)
+        struct Cursor { int pp, f, row, rown; };
+        auto row_at = [&](const int32_t* idx, int pp) -> int {
+            const int32_t r = idx[pos0 + (pp < P ? pp : P - 1)];
+            return (tv && pp < P) ? (r < 0 ? 0 : r) : -1;
+        };
+        auto cur_init = [&](Cursor& cu, const int32_t* idx) { cu.pp = 0; cu.f = 4 * g; cu.row = row_at(idx, 0); cu.rown = row_at(idx, 1); };
+        auto gather = [&](const float* table, int F, Cursor& cu, const int32_t* idx) -> f4 {
+            // DyGFormer.py:259-261; an absent position reads the zero word.  The select is arithmetic on the address (a ?: on the pointers
+            // comes back as a branch around the address computation, which would end the scheduling region of the step)
+            const uintptr_t pz = reinterpret_cast<uintptr_t>(g_zero16);
+            const uintptr_t pt = reinterpret_cast<uintptr_t>(table + (size_t)(cu.row >= 0 ? cu.row : 0) * F + cu.f);
+            const f4 v = ldg4(reinterpret_cast<const float*>(pz + ((pt - pz) & (cu.row >= 0 ? ~uintptr_t(0) : uintptr_t(0)))));
+            ++pj_young;
             cu.f += 16;
-            if (cu.f >= F) { cu.f -= F; ++cu.pp; cu.row = row_of(idx, cu.pp); }
+            const bool wrap = cu.f >= F;
+            cu.f = wrap ? cu.f - F : cu.f;
+            cu.pp += wrap ? 1 : 0;
+            cu.row = wrap ? cu.rown : cu.row;
+            cu.rown = row_at(idx, cu.pp + 1);
+            return v;
         };
-        // one projection step: fragments of this step in fa[PAR] (read now if `first`/fresh), those of the next step of
-        // the same channel and slab are read into fa[PAR^1] while this step multiplies
-        auto mma_step = [&](auto LOCAL0, const int PR, f4 (&fa)[2][4], bool first, bool more, const f4 bcur) {
-            constexpr int L0 = decltype(LOCAL0)::value;
-            bool fresh;
-            const float* fr = slab_step(fresh);
-            if (work) {
-                if (first || fresh) {
+        auto prefill = [&](f4 (&bq)[GS], Cursor& cu, const float* table, const int32_t* idx, int F) {
+            cur_init(cu, idx);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) fa[PR][v] = lds4(fr + v * kFrag);
-                }
-                if (more && sstep < a.slab_chunks) {
+            for (int u = 0; u < GS; ++u) bq[u] = gather(table, F, cu, idx);
+        };
+        auto g_group = [&](auto L0c, auto NSc, auto FRESHc, f4 (&fa)[2][4], f4 (&bq)[GS], Cursor& cu, const float* table, const int32_t* idx, int F) {
+            constexpr int L0 = decltype(L0c)::value, NS = decltype(NSc)::value;
+            const float* fr = frag_ptr();
+            if (decltype(FRESHc)::value) read_frags(fa[0], fr);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) fa[PR ^ 1][v] = lds4(fr + (4 + v) * kFrag);
-                }
-                __builtin_amdgcn_sched_barrier(0);          // operand loads of later steps stay issued ABOVE this step's MFMAs
-                mma_group<4>(&x[L0], fa[PR], bcur);
+            for (int u = 0; u < NS; ++u) {
+                const f4 bcur = bq[u];
+                bq[u] = gather(table, F, cu, idx);             // chunk + GS (zeros beyond the patch)
+                frags_ahead(NSc, u, fr, fa, true);
+                // operand loads of later steps stay issued ABOVE this step's MFMAs.  (Measured and not kept: the gather and the cursor arithmetic
+                // scheduled into the shadow of the step's own MFMAs by sched_group_barrier, as the time channel does with its cosines —
+                // node / edge channel 126 k -> 138 k cycles per 86 chunks at L = 512: the address arithmetic is short enough for the SIMD's
+                // other wave to cover, and spreading it stretches the wave's MFMA block.)
+                __builtin_amdgcn_sched_barrier(0);
+                mma_group<4>(&x[L0], fa[u & 1], bcur);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        // gathered channel: bq[] holds the operands of the next DQ chunks
-        auto prefill = [&](f4 (&bq)[DQ], Cursor& cu, const float* table, const int32_t* idx, int F) {
-            cu = Cursor{0, 4 * g, row_of(idx, 0)};
-            if (work) {
-#pragma unroll
-                for (int u = 0; u < DQ; ++u) { bq[u] = gather(table, F, cu); step_gather(cu, idx, F); }
-            }
-        };
-        auto run_gathered = [&](auto LOCAL0, f4 (&bq)[DQ], Cursor& cu, int nchunk, const float* table, const int32_t* idx, int F) {
+        auto run_gathered = [&](auto L0c, f4 (&bq)[GS], Cursor& cu, int n, const float* table, const int32_t* idx, int F) {
             f4 fa[2][4];
-            for (int kc0 = 0; kc0 < nchunk; kc0 += DQ) {
-#pragma unroll
-                for (int u = 0; u < DQ; ++u) {
-                    if (kc0 + u < nchunk) {
-                        const f4 bcur = bq[u];
-                        if (work) { bq[u] = gather(table, F, cu); step_gather(cu, idx, F); }   // chunk kc0+u+DQ (zeros beyond the patch)
-                        mma_step(LOCAL0, u & 1, fa, kc0 + u == 0, kc0 + u + 1 < nchunk, bcur);
-                    }
-                }
+            const int ng = n / GS, rem = n % GS;
+            if (ng > 0) {
+                g_group(L0c, integral_constant<int, GS>{}, std::true_type{}, fa, bq, cu, table, idx, F);
+                for (int i = 1; i < ng; ++i) g_group(L0c, integral_constant<int, GS>{}, std::false_type{}, fa, bq, cu, table, idx, F);
             }
+            if (rem == 1) g_group(L0c, integral_constant<int, 1>{}, std::true_type{}, fa, bq, cu, table, idx, F);
+            else if (rem == 2) g_group(L0c, integral_constant<int, 2>{}, std::true_type{}, fa, bq, cu, table, idx, F);
+            else if (rem == 3) g_group(L0c, integral_constant<int, 3>{}, std::true_type{}, fa, bq, cu, table, idx, F);
         };
-        // computed channel (time encoding, co-occurrence features): operands made DC chunks ahead (the LUT reads of the
-        // co-occurrence features are L2 round trips)
-        constexpr int DC = 4;
-        auto run_computed = [&](auto LOCAL0, int nchunk, auto bfn) {
-            f4 br[DC];
-            f4 fa[2][4];
-            if (work) {
-#pragma unroll
-                for (int u = 0; u < DC; ++u) br[u] = bfn();
-            }
-            for (int kc0 = 0; kc0 < nchunk; kc0 += DC) {
-#pragma unroll
-                for (int u = 0; u < DC; ++u) {
-                    if (kc0 + u < nchunk) {
-                        const f4 bcur = br[u];
-                        if (work) br[u] = bfn();
-                        mma_step(LOCAL0, u & 1, fa, kc0 + u == 0, kc0 + u + 1 < nchunk, bcur);
-                    }
-                }
-            }
+
+        // ---- time encoding (modules.py:27-39, DyGFormer.py:263-266): the cursor runs one chunk ahead of the MFMAs; the four cosines of the
+        // next chunk are computed in the shadow of this chunk's 16 MFMAs (sched_group_barrier: 1 MFMA, 7 VALU, ...), (valid, dt) of the next
+        // patch position are read one step ahead like the gather rows
+        struct TCur { int pp, f; float dt, dtn; bool ok, okn; };
+        auto tpos_at = [&](int pp, float& dt, bool& ok) {
+            const int q = pos0 + (pp < P ? pp : P - 1);
+            const int32_t id = ids[q];
+            const float d = dts[q];
+            ok = tv && pp < P && id > 0;                                                             // DyGFormer.py:266
+            dt = ok ? d : 0.f;
         };
-        // time encoding: (valid, dt) of the current patch position are cached like the gather row
-        struct TCur { int pp, f; float dt; bool ok; };
-        auto tpos = [&](TCur& tc) {
-            tc.ok = tv && tc.pp < P && ids[pos0 + tc.pp] > 0;                                        // DyGFormer.py:266
-            tc.dt = tc.ok ? dts[pos0 + tc.pp] : 0.f;
-        };
-        TCur tc{0, 4 * g, 0.f, false};
-        tpos(tc);
-        auto timef = [&]() -> f4 {
-            f4 r = zero4();
-            if (tc.ok) {
-                const f4 w = lds4(tws + tc.f), bb = lds4(tws + a.Ft + tc.f);
-                r.x = cos_time(fmaf(tc.dt, w.x, bb.x)); r.y = cos_time(fmaf(tc.dt, w.y, bb.y));
-                r.z = cos_time(fmaf(tc.dt, w.z, bb.z)); r.w = cos_time(fmaf(tc.dt, w.w, bb.w));
-            }
+        auto t_advance = [&](TCur& tc) {
             tc.f += 16;
-            if (tc.f >= a.Ft) { tc.f -= a.Ft; ++tc.pp; tpos(tc); }
-            return r;
+            const bool wrap = tc.f >= a.Ft;
+            tc.f = wrap ? tc.f - a.Ft : tc.f;
+            tc.pp += wrap ? 1 : 0;
+            tc.dt = wrap ? tc.dtn : tc.dt;
+            tc.ok = wrap ? tc.okn : tc.ok;
+            tpos_at(tc.pp + 1, tc.dtn, tc.okn);
         };
-        // co-occurrence features: k = 50*pp + j is not 4-aligned per position, so every element finds its own (pp, j);
-        // k/50 by multiply-shift (exact for k < 12000)
-        int kco = 4 * g;
-        auto coocf = [&]() -> f4 {
-            f4 r;
+        auto t_finish = [&](const bool ok, const f4 arg, f4 cs) -> f4 {      // rare: an argument beyond the fast cosine's range takes libm's
+            if (!(fabsf(arg.x) <= 3.0e7f && fabsf(arg.y) <= 3.0e7f && fabsf(arg.z) <= 3.0e7f && fabsf(arg.w) <= 3.0e7f)) {
+                cs.x = cos_time(arg.x); cs.y = cos_time(arg.y); cs.z = cos_time(arg.z); cs.w = cos_time(arg.w);
+            }
+            return ok ? cs : zero4();
+        };
+        auto t_group = [&](auto L0c, auto NSc, auto FRESHc, f4 (&fa)[2][4], f4& bnx, TCur& tc) {
+            constexpr int L0 = decltype(L0c)::value, NS = decltype(NSc)::value;
+            const float* fr = frag_ptr();
+            if (decltype(FRESHc)::value) read_frags(fa[0], fr);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int u = 0; u < NS; ++u) {
+                const f4 bcur = bnx;
+                const f4 w = lds4(tws + tc.f), bb = lds4(tws + a.Ft + tc.f);       // of the next chunk
+                frags_ahead(NSc, u, fr, fa, false);
+                __builtin_amdgcn_sched_barrier(0);
+                const f2 dt2 = {tc.dt, tc.dt};
+                const f2 a01 = pk_fma(dt2, f2{w.x, w.y}, f2{bb.x, bb.y}), a23 = pk_fma(dt2, f2{w.z, w.w}, f2{bb.z, bb.w});
+                const f2 c01 = cos_time_fast2(a01), c23 = cos_time_fast2(a23);
+                const f4 arg = {a01.x, a01.y, a23.x, a23.y}, cs = {c01.x, c01.y, c23.x, c23.y};
+                const bool okc = tc.ok;
+                t_advance(tc);                                 // the cursor arithmetic and the next position's (valid, dt) reads: same region
+                mma_group<4>(&x[L0], fa[u & 1], bcur);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);     // six VALU of the cosines in its shadow
+                    if (i == 13) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // the next position's id and dt
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                bnx = t_finish(okc, arg, cs);
+            }
+        };
+        auto run_time = [&](auto L0c, int n) {
+            f4 fa[2][4];
+            TCur tc{0, 4 * g, 0.f, 0.f, false, false};
+            tpos_at(0, tc.dt, tc.ok);
+            tpos_at(1, tc.dtn, tc.okn);
+            f4 bnx;
+            {   // chunk 0 (not overlapped)
+                const f4 w = lds4(tws + tc.f), bb = lds4(tws + a.Ft + tc.f);
+                f4 arg;
+                arg.x = fmaf(tc.dt, w.x, bb.x); arg.y = fmaf(tc.dt, w.y, bb.y); arg.z = fmaf(tc.dt, w.z, bb.z); arg.w = fmaf(tc.dt, w.w, bb.w);
+                f4 cs;
+                cs.x = cos_time_fast(arg.x); cs.y = cos_time_fast(arg.y); cs.z = cos_time_fast(arg.z); cs.w = cos_time_fast(arg.w);
+                bnx = t_finish(tc.ok, arg, cs);
+                t_advance(tc);
+            }
+            const int ng = n / GS, rem = n % GS;
+            if (ng > 0) {
+                t_group(L0c, integral_constant<int, GS>{}, std::true_type{}, fa, bnx, tc);
+                for (int i = 1; i < ng; ++i) t_group(L0c, integral_constant<int, GS>{}, std::false_type{}, fa, bnx, tc);
+            }
+            if (rem == 1) t_group(L0c, integral_constant<int, 1>{}, std::true_type{}, fa, bnx, tc);
+            else if (rem == 2) t_group(L0c, integral_constant<int, 2>{}, std::true_type{}, fa, bnx, tc);
+            else if (rem == 3) t_group(L0c, integral_constant<int, 3>{}, std::true_type{}, fa, bnx, tc);
+        };
+
+        // ---- co-occurrence features (DyGFormer.py:395-415): k = 50*pp + j is not 4-aligned per position, so every element finds its own
+        // (pp, j); k/50 by multiply-shift (exact for k < 12000).  The two LUT rows' values of a chunk are loaded two steps ahead (L2 round trips).
+        struct CQ { f4 u, v; };
+        int kco = 4 * g;
+        auto cooc_issue = [&]() -> CQ {
+            CQ r;
+#pragma unroll
+            for (int t = 0; t < 4; t += 2) {             // k and 50 are even: the pair (k, k + 1) lies inside one position, its LUT address is 8-byte aligned
                 const int k = kco + t;
                 const int pp = (k * 1311) >> 16;
-                float v = 0.f;
-                if (tv && pp < P) {
-                    const int j = k - pp * kC;
-                    v = a.lut[(size_t)c0[pos0 + pp] * kC + j] + a.lut[(size_t)c1[pos0 + pp] * kC + j];   // DyGFormer.py:409-411
-                }
-                r[t] = v;
+                const bool ok = tv && pp < P;
+                const int q = pos0 + (pp < P ? pp : P - 1);
+                const int j = k - pp * kC;
+                const uintptr_t pz = reinterpret_cast<uintptr_t>(g_zero16), m = ok ? ~uintptr_t(0) : uintptr_t(0);
+                const uintptr_t p0 = reinterpret_cast<uintptr_t>(a.lut + (size_t)c0[q] * kC + j), p1 = reinterpret_cast<uintptr_t>(a.lut + (size_t)c1[q] * kC + j);
+                const f2 v0 = *reinterpret_cast<const f2*>(pz + ((p0 - pz) & m));                   // DyGFormer.py:409-411
+                const f2 v1 = *reinterpret_cast<const f2*>(pz + ((p1 - pz) & m));
+                r.u[t] = v0.x; r.u[t + 1] = v0.y; r.v[t] = v1.x; r.v[t + 1] = v1.y;
             }
             kco += 16;
             return r;
         };
-        f4 bq[DQ];
+        auto c_group = [&](auto L0c, auto NSc, auto FRESHc, f4 (&fa)[2][4], CQ (&cq)[2]) {
+            constexpr int L0 = decltype(L0c)::value, NS = decltype(NSc)::value;
+            const float* fr = frag_ptr();
+            if (decltype(FRESHc)::value) read_frags(fa[0], fr);
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const f4 bcur = cq[u & 1].u + cq[u & 1].v;
+                cq[u & 1] = cooc_issue();                       // chunk + 2
+                frags_ahead(NSc, u, fr, fa, false);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_group<4>(&x[L0], fa[u & 1], bcur);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto run_cooc = [&](auto L0c, int n) {
+            f4 fa[2][4];
+            CQ cq[2];
+            cq[0] = cooc_issue();
+            cq[1] = cooc_issue();
+            const int ng = n / GS, rem = n % GS;
+            if (ng > 0) {
+                c_group(L0c, integral_constant<int, GS>{}, std::true_type{}, fa, cq);
+                for (int i = 1; i < ng; ++i) c_group(L0c, integral_constant<int, GS>{}, std::false_type{}, fa, cq);
+            }
+            if (rem == 1) c_group(L0c, integral_constant<int, 1>{}, std::true_type{}, fa, cq);
+            else if (rem == 2) c_group(L0c, integral_constant<int, 2>{}, std::true_type{}, fa, cq);
+            else if (rem == 3) c_group(L0c, integral_constant<int, 3>{}, std::true_type{}, fa, cq);
+        };
+
+        // Channel order node, time, edge, cooc: the edge gathers are issued before the time channel computes its cosines.  A wave whose
+        // tile is empty, or a source tile shared with the first pair (f4), only keeps the barriers of the channel.
+        const bool work = active && !src_shared;
+        f4 bq[GS];
         Cursor cu;
-        prefill(bq, cu, a.node_feat, ids, a.Fn);
+        if (work) prefill(bq, cu, a.node_feat, ids, a.Fn);
         TACC(T_PROJ);
-        run_gathered(std::integral_constant<int, 0>{}, bq, cu, a.nchunk[0], a.node_feat, ids, a.Fn);
-        prefill(bq, cu, a.edge_feat, eids, a.Fe);            // in flight while the time channel runs
+        if (work) run_gathered(integral_constant<int, 0>{}, bq, cu, a.nchunk[0], a.node_feat, ids, a.Fn); else run_idle(a.nchunk[0]);
+        if (work) prefill(bq, cu, a.edge_feat, eids, a.Fe);            // in flight while the time channel runs
         TACC(T_PNODE);
-        run_computed(std::integral_constant<int, 6>{}, a.nchunk[2], timef);
+        if (work) run_time(integral_constant<int, 6>{}, a.nchunk[2]); else run_idle(a.nchunk[2]);
         TACC(T_PTIME);
-        run_gathered(std::integral_constant<int, 3>{}, bq, cu, a.nchunk[1], a.edge_feat, eids, a.Fe);
+        if (work) run_gathered(integral_constant<int, 3>{}, bq, cu, a.nchunk[1], a.edge_feat, eids, a.Fe); else run_idle(a.nchunk[1]);
         TACC(T_PEDGE);
-        work = active;
-        run_computed(std::integral_constant<int, 9>{}, a.nchunk[3], coocf);
+        if (active) run_cooc(integral_constant<int, 9>{}, a.nchunk[3]); else run_idle(a.nchunk[3]);
         TACC(T_PCOOC);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // gathers issued past the end of a channel
     }
     TACC(T_PROJ);
     __syncthreads();     // everyone is done with the window arrays and the slab
@@ -1424,7 +1556,6 @@ __device__ __forceinline__ void ln_backward(const f4 (&dxn)[kNT], const float* x
         __builtin_amdgcn_sched_barrier(0);
     }
 }
-__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};      // LDS-DMA source for rows that do not exist
 struct AttnBwdArgs {
     const float* stream; int nstages;
     int64_t B; int T;
@@ -1805,15 +1936,18 @@ static int64_t bwd_attn_frags() {
     return (int64_t)sb.frags.size();
 }
 
-// projection fragments in step order (channels node, time, edge, cooc; 4 tiles per k-chunk), staged by slabs
+// projection fragments in step order (channels node, time, edge, cooc; 4 tiles per k-chunk slot), staged through two LDS halves
+static int proj_slots(int nchunk) { return (nchunk + 3) / 4 * 4; }
 static void build_proj(const Dims& d, const dygnn_dygformer_weights* w, StreamBuilder& sb) {
     const float* pw[4] = {w->proj_node_w, w->proj_edge_w, w->proj_time_w, w->proj_cooc_w};
     const int K[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * d.C};
     const int order[4] = {0, 2, 1, 3};
     for (int o = 0; o < 4; ++o) {
         const int ch = order[o], t0 = (kC * ch) / 16;
-        for (int kc = 0; kc < (K[ch] + 15) / 16; ++kc)
+        const int n = (K[ch] + 15) / 16;
+        for (int kc = 0; kc < n; ++kc)
             for (int u = 0; u < 4; ++u) sb.put(pw[ch], K[ch], 16 * (t0 + u) - kC * ch, kC, 16 * kc, K[ch]);
+        sb.pad(4 * (proj_slots(n) - n));           // every channel occupies whole groups of four slots (the kernel's loop bodies are groups)
     }
 }
 
@@ -1864,7 +1998,7 @@ static PackLayout3 make_layout3(const Dims& d) {
     f.aux = take((size_t)f.naux * kFrag);
     const int K[4] = {d.P * d.Fn, d.P * d.Fe, d.P * d.Ft, d.P * d.C};
     f.nproj = 0;
-    for (int ch = 0; ch < 4; ++ch) f.nproj += 4 * (int64_t)((K[ch] + 15) / 16);
+    for (int ch = 0; ch < 4; ++ch) f.nproj += 4 * (int64_t)proj_slots((K[ch] + 15) / 16);
     f.proj = take((size_t)f.nproj * kFrag);
     f.bwd_nstages = (int)((kBwdFfnFrags + kStage - 1) / kStage);
     for (int l = 0; l < d.NL; ++l) f.bwd[l] = take((size_t)(f.bwd_nstages + 1) * kStage * kFrag);
@@ -1880,7 +2014,8 @@ static PackLayout3 make_layout3(const Dims& d) {
     else if (d.Tmax <= 128 && per_pair <= kScratchFloats) { f.np = 1; f.slab_in_ring = 1; }
     if (f.np) {
         f.scr_floats = f.np * per_pair;
-        f.slab_chunks = f.slab_in_ring ? kRing / 4 : (kScratchFloats - f.scr_floats) / (4 * kFrag);
+        // two halves of slab_chunks slots each, whole groups of four slots
+        f.slab_chunks = (f.slab_in_ring ? kRing / 4 : (kScratchFloats - f.scr_floats) / (4 * kFrag)) / 8 * 4;
     }
     f.total = o;
     return f;

@@ -14,11 +14,13 @@ os.environ.setdefault("DYGNN_LIB_VARIANT", "stamps")
 from dyglib_amd import DyGFormer, get_neighbor_sampler, synthetic as syn  # noqa: E402
 
 dev = "cuda:0"
-data, nf, ef = syn.make_bipartite_graph(8227, 1000, 157474, seed=0)
-params = syn.make_dygformer_params(0, patch_size=2)
+# PHASE_WORKLOAD=lastfm: BASELINE config 4's shape (L=512, P=8: one 128-token pair per workgroup, k_dygformer_fused3<8>)
+WL = {"wikipedia": (8227, 1000, 157474, 64, 2, "normal"), "lastfm": (980, 1000, 1293103, 512, 8, "zeros")}[os.environ.get("PHASE_WORKLOAD", "wikipedia")]
+data, nf, ef = syn.make_bipartite_graph(WL[0], WL[1], WL[2], seed=0, edge_feat_kind=WL[5])
+params = syn.make_dygformer_params(0, patch_size=WL[4])
 sampler = get_neighbor_sampler(data, "recent", seed=1, device=dev)
-model = DyGFormer(nf, ef, sampler, 100, 50, patch_size=2, num_layers=2, num_heads=2, dropout=0.1,
-                  max_input_sequence_length=64, device=dev)
+model = DyGFormer(nf, ef, sampler, 100, 50, patch_size=WL[4], num_layers=2, num_heads=2, dropout=0.1,
+                  max_input_sequence_length=WL[3], device=dev)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
 model = model.to(dev).eval()
 model.impl = int(os.environ.get("PHASE_IMPL", "3"))
