@@ -160,7 +160,7 @@ __device__ __forceinline__ float cos_time_fast(float x) {      // |x| <= 3e7 (br
 }
 __device__ __forceinline__ float cos_time(float x) { return fabsf(x) <= 3.0e7f ? cos_time_fast(x) : cosf(x); }
 // the same operations on two arguments at once, written on 2-vectors so that hipcc emits packed fp32 instructions (v_pk_mul / v_pk_fma /
-// v_pk_add_f32: two results per issue slot; the time channel of the projection is bound by VALU issue, not by the matrix pipe)
+// v_pk_add_f32: two results in ~1.6 issue slots, tools/coissue_ubench.hip; VALU instructions take matrix-pipe time in this kernel)
 using f2 = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 cos_time_fast2(f2 x) {
@@ -213,6 +213,7 @@ struct Args {
     int slab_chunks;              // k-chunk slots per LDS HALF (a multiple of 4; two halves)
     int scr_floats;               // LDS floats reserved for the window arrays (the slab follows)
     int slab_in_ring;             // long windows (e.g. L = 2048): the slab borrows the weight ring, whose stream then opens after the prologue
+    int tab_off, tab_slots, tab_bits;   // co-occurrence table per pair (LDS word offset, slots = 2^bits; 0: counts by scanning the rows)
     const float* bias_x;          // [208] projection biases in model-dim order
     const float* outfrag;         // output layer as fragments [ceil(Fn/16) tiles][13 k-chunks]
     LayerP layer[DYGNN_MAX_LAYERS];
@@ -569,9 +570,45 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_dygformer_fused3(c
             ids[p] = id; eids[p] = e; dts[p] = dt;
         }
     }
+    // long windows: an open-addressing table [keys | counts] per pair behind the projection halves (a.tab_slots > 0), cleared here
+    int32_t* tkeys = reinterpret_cast<int32_t*>(lds) + a.tab_off + pi * 2 * a.tab_slots;
+    int32_t* tcnts = tkeys + a.tab_slots;
+    for (int i = ptid; i < a.tab_slots; i += PT) { tkeys[i] = -2; tcnts[i] = 0; }
     __syncthreads();
-    // ---- co-occurrence counts (DyGFormer.py:337-393): one thread per position, 4 ids per broadcast LDS read
-    if (pair_ok) {
+    // ---- co-occurrence counts (DyGFormer.py:337-393)
+    if (a.tab_slots > 0) {
+        // Windows of hundreds of positions (L = 512: 1,024 positions per pair, a million comparisons by the scan below = 5 % of the kernel):
+        // every position inserts its id into the table (linear probing; the slot's count word holds the source-side count in its low
+        // half, the destination-side count in its high half), one barrier, every position reads its id's slot.  Exact integers.
+        const uint32_t mask = (uint32_t)a.tab_slots - 1;
+        const int shift = 32 - a.tab_bits;
+        if (pair_ok) {
+            for (int p = ptid; p < SA; p += PT) {
+                const int32_t v = ids[p];
+                if (v <= 0) continue;
+                uint32_t sl = ((uint32_t)v * 2654435761u) >> shift;
+                for (int it = 0; it < a.tab_slots; ++it, sl = (sl + 1) & mask) {
+                    const int32_t old = atomicCAS(&tkeys[sl], -2, v);
+                    if (old == -2 || old == v) { atomicAdd(&tcnts[sl], p >= SsA ? 0x10000 : 1); break; }
+                }
+            }
+        }
+        __syncthreads();
+        if (pair_ok) {
+            for (int p = ptid; p < SA; p += PT) {
+                const int32_t v = ids[p];
+                int32_t cs = 0, cdn = 0;
+                if (v > 0) {
+                    uint32_t sl = ((uint32_t)v * 2654435761u) >> shift;
+                    for (int it = 0; it < a.tab_slots && tkeys[sl] != v; ++it) sl = (sl + 1) & mask;
+                    const int32_t w = tcnts[sl];
+                    cs = w & 0xffff; cdn = w >> 16;
+                }
+                c0[p] = cs; c1[p] = cdn;
+            }
+        }
+    } else if (pair_ok) {
+        // one thread per position, 4 ids per broadcast LDS read
         for (int p = ptid; p < SA; p += PT) {
             const int32_t v = ids[p];
             int32_t cs = 0, cdn = 0;
@@ -709,10 +746,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_dygformer_fused3(c
             else if (rem == 3) g_group(L0c, integral_constant<int, 3>{}, std::true_type{}, fa, bq, cu, table, idx, F);
         };
 
-        // ---- time encoding (modules.py:27-39, DyGFormer.py:263-266): the cursor runs one chunk ahead of the MFMAs; the four cosines of the
-        // next chunk are computed in the shadow of this chunk's 16 MFMAs (sched_group_barrier: 1 MFMA, 7 VALU, ...), (valid, dt) of the next
-        // patch position are read one step ahead like the gather rows
-        struct TCur { int pp, f; float dt, dtn; bool ok, okn; };
+        // ---- time encoding (modules.py:27-39, DyGFormer.py:263-266): the cursor runs one chunk ahead of the MFMAs; (valid, dt) of the next patch
+        // position and the next chunk's w / b are read one step ahead like the gather rows.  What the channel costs beyond its MFMAs is the
+        // instruction count of the cosines: on this chip a VALU instruction does not issue in the shadow of an fp32 MFMA — not of the same wave,
+        // not of the SIMD's other wave (tools/coissue_ubench.hip: 16 MFMAs + 64 v_fma_f32 take the SUM of their times, 1 or 2 waves per SIMD) —
+        // so interleaving them (sched_group_barrier) bought nothing; the cosines are evaluated two at a time on packed fp32 instructions
+        struct TCur { int pp, f; float dt; bool ok; int32_t idn; float dn; f4 w, bb; };      // idn, dn: id and dt of position pp + 1 as read from LDS; w, bb: encoder weights / biases of features f .. f+3
         auto tpos_at = [&](int pp, float& dt, bool& ok) {
             const int q = pos0 + (pp < P ? pp : P - 1);
             const int32_t id = ids[q];
@@ -720,14 +759,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_dygformer_fused3(c
             ok = tv && pp < P && id > 0;                                                             // DyGFormer.py:266
             dt = ok ? d : 0.f;
         };
+        // the reads of the next position are issued here and USED by the next call: nothing in a step waits for an LDS read of its own
         auto t_advance = [&](TCur& tc) {
             tc.f += 16;
             const bool wrap = tc.f >= a.Ft;
             tc.f = wrap ? tc.f - a.Ft : tc.f;
+            const bool okn = tv && tc.pp + 1 < P && tc.idn > 0;
+            tc.dt = wrap ? (okn ? tc.dn : 0.f) : tc.dt;
+            tc.ok = wrap ? okn : tc.ok;
             tc.pp += wrap ? 1 : 0;
-            tc.dt = wrap ? tc.dtn : tc.dt;
-            tc.ok = wrap ? tc.okn : tc.ok;
-            tpos_at(tc.pp + 1, tc.dtn, tc.okn);
+            const int q = pos0 + (tc.pp + 1 < P ? tc.pp + 1 : P - 1);
+            tc.idn = ids[q];
+            tc.dn = dts[q];
+            tc.w = lds4(tws + tc.f);
+            tc.bb = lds4(tws + a.Ft + tc.f);
         };
         auto t_finish = [&](const bool ok, const f4 arg, f4 cs) -> f4 {      // rare: an argument beyond the fast cosine's range takes libm's
             if (!(fabsf(arg.x) <= 3.0e7f && fabsf(arg.y) <= 3.0e7f && fabsf(arg.z) <= 3.0e7f && fabsf(arg.w) <= 3.0e7f)) {
@@ -742,7 +787,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_dygformer_fused3(c
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
                 const f4 bcur = bnx;
-                const f4 w = lds4(tws + tc.f), bb = lds4(tws + a.Ft + tc.f);       // of the next chunk
+                const f4 w = tc.w, bb = tc.bb;                  // of the next chunk (read during the previous step)
                 frags_ahead(NSc, u, fr, fa, false);
                 __builtin_amdgcn_sched_barrier(0);
                 const f2 dt2 = {tc.dt, tc.dt};
@@ -752,21 +797,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_dygformer_fused3(c
                 const bool okc = tc.ok;
                 t_advance(tc);                                 // the cursor arithmetic and the next position's (valid, dt) reads: same region
                 mma_group<4>(&x[L0], fa[u & 1], bcur);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);     // six VALU of the cosines in its shadow
-                    if (i == 13) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // the next position's id and dt
-                }
                 __builtin_amdgcn_sched_barrier(0);
                 bnx = t_finish(okc, arg, cs);
             }
         };
         auto run_time = [&](auto L0c, int n) {
             f4 fa[2][4];
-            TCur tc{0, 4 * g, 0.f, 0.f, false, false};
+            TCur tc{0, 4 * g, 0.f, false, 0, 0.f, zero4(), zero4()};
             tpos_at(0, tc.dt, tc.ok);
-            tpos_at(1, tc.dtn, tc.okn);
+            { const int q = pos0 + (1 < P ? 1 : P - 1); tc.idn = ids[q]; tc.dn = dts[q]; }
             f4 bnx;
             {   // chunk 0 (not overlapped)
                 const f4 w = lds4(tws + tc.f), bb = lds4(tws + a.Ft + tc.f);
@@ -1965,6 +2004,7 @@ struct PackLayout3 {       // float offsets relative to PackedLayout.fused3
     size_t proj; int64_t nproj;                    // projection fragments
     int scr_floats, slab_chunks;                   // LDS split of the K/V region during the prologue
     int np, slab_in_ring;                          // pairs per workgroup (0: shape unsupported); slab placed in the weight ring
+    int tab_off, tab_slots, tab_bits;              // co-occurrence table (long windows): LDS word offset, slots per pair
     size_t bwd[DYGNN_MAX_LAYERS]; int bwd_nstages;  // per layer: the backward stream of its FFN block (training only)
     size_t bwa[DYGNN_MAX_LAYERS]; int bwa_nstages; int64_t bwa_frags;      // ... and of its attention block
     size_t desc;           // FragDesc table (device copy), 8-byte aligned
@@ -2008,7 +2048,7 @@ static PackLayout3 make_layout3(const Dims& d) {
     f.desc = take(((size_t)(f.nfrag + f.naux + f.nproj + d.NL * (kBwdFfnFrags + f.bwa_frags)) * sizeof(FragDesc) + 3) / 4);
     // prologue LDS split: pairs per workgroup, window arrays (5 x 2 sides x Smax ints per pair), projection slab
     const int per_pair = 5 * 2 * ((d.Smax + 3) & ~3);
-    f.np = 0; f.slab_in_ring = 0; f.scr_floats = 0; f.slab_chunks = 0;
+    f.np = 0; f.slab_in_ring = 0; f.scr_floats = 0; f.slab_chunks = 0; f.tab_off = 0; f.tab_slots = 0; f.tab_bits = 0;
     if (d.Tmax <= 64 && 2 * per_pair + 8 * 4 * kFrag <= kScratchFloats) f.np = 2;
     else if (d.Tmax <= 128 && per_pair + 8 * 4 * kFrag <= kScratchFloats) f.np = 1;
     else if (d.Tmax <= 128 && per_pair <= kScratchFloats) { f.np = 1; f.slab_in_ring = 1; }
@@ -2016,6 +2056,13 @@ static PackLayout3 make_layout3(const Dims& d) {
         f.scr_floats = f.np * per_pair;
         // two halves of slab_chunks slots each, whole groups of four slots
         f.slab_chunks = (f.slab_in_ring ? kRing / 4 : (kScratchFloats - f.scr_floats) / (4 * kFrag)) / 8 * 4;
+        // what the window arrays and the two halves leave of the K/V region: a co-occurrence table of >= 2 x positions slots per pair, for
+        // windows long enough that two barriers cost less than the all-pairs scan
+        f.tab_off = f.scr_floats + (f.slab_in_ring ? 0 : 2 * f.slab_chunks * 4 * kFrag);
+        const int positions = 2 * ((d.Smax + 3) & ~3), words = (kScratchFloats - f.tab_off) / f.np;
+        int bits = 0;
+        while ((2 << (bits + 1)) <= words) ++bits;          // slots = 2^bits, two words per slot
+        if (positions >= 512 && (1 << bits) >= 2 * positions) { f.tab_slots = 1 << bits; f.tab_bits = bits; }
     }
     f.total = o;
     return f;
@@ -2142,6 +2189,7 @@ static int fused3_args(const Dims& d, const PackedLayout& pl, const dygnn_dygfor
     a.outfrag = base + f.aux;
     a.projw = base + f.proj; a.proj_frags = (int)f.nproj; a.slab_chunks = f.slab_chunks; a.scr_floats = f.scr_floats;
     a.slab_in_ring = f.slab_in_ring;
+    a.tab_off = f.tab_off; a.tab_slots = f.tab_slots; a.tab_bits = f.tab_bits;
     a.outT = packed + pl.outputT; a.outb = w->output_b;
     a.out_src = out_src; a.out_dst = out_dst;
     a.tap_enc = taps ? taps->encoder_input : nullptr;

@@ -490,9 +490,10 @@ int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb,
 // ------------------------------------------------------------------------------------------------
 struct DwProblem { const float* A; const float* B; float* C; float* colsum; int lda, ldb, ldc, M, N, ncw; };
 constexpr int kDwMaxProblems = 4 * DYGNN_MAX_LAYERS + 4, kDwMaxItems = 32 * DYGNN_MAX_LAYERS + 16, kDwNS = 3, kDwStage = 22 * 256, kDwLdsBytes = kDwNS * kDwStage * 4;
+static_assert(kDwMaxProblems <= (1 << 20), "item code: problem index above bit 12");
 struct DwArgs {
     DwProblem prob[kDwMaxProblems];
-    unsigned short item[kDwMaxItems];      // problem << 12 | m-group << 6 | n-chunk
+    unsigned int item[kDwMaxItems];        // problem << 12 | m-group << 6 | n-chunk (up to kDwMaxProblems = 36 problems: a 16-bit code held 16)
     int nitems, K, kchunk;
 };
 __device__ __forceinline__ void dw_dma(const float* gsrc_lane, int lds_float_off_uniform) {      // see v3::dma_frag (dygformer_fused3.hip)
@@ -636,7 +637,7 @@ struct DwList {
         if (!aligned || nprob >= kDwMaxProblems || mg > 64 || nch > 64 || args.nitems + mg * nch > kDwMaxItems) return false;
         args.prob[nprob] = DwProblem{A, B, C, colsum, lda, ldb, ldc, M, N, ncw};
         for (int x = 0; x < mg; ++x)
-            for (int y = 0; y < nch; ++y) args.item[args.nitems++] = (unsigned short)(nprob << 12 | x << 6 | y);
+            for (int y = 0; y < nch; ++y) args.item[args.nitems++] = (unsigned)nprob << 12 | (unsigned)x << 6 | (unsigned)y;
         ++nprob;
         return true;
     }

@@ -679,7 +679,9 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
             chain::PostArgs po{F32(p.z), h_lower, node_feat, I32(p.ids[l - 1]), lmap, nl, w->time_w, w->time_b, F32(p.pack), y.v, y.r, y.f1, y.f2, Lw.res_b, Lw.ln_w,
                                Lw.ln_b, Lw.fc1_b, Lw.fc2_b, h_out, n, p.Fn, p.Ft, p.Dkv, p.H, nullptr,
                                attn_in_post ? F32(p.qk) : nullptr, edge_feat, I32(p.eid[l]), F32(p.dt[l]), p.k, p.Fe, scale};
-            if (const char* st_env = getenv("DYGNN_CHAIN_STAMPS")) po.stamps = reinterpret_cast<unsigned long long*>(strtoull(st_env, nullptr, 0));      // tools/chain_stamps.py
+#ifdef DYGNN_STAMPS      // diagnostic build only (tools/chain_stamps.py, DYGNN_LIB_VARIANT=stamps): the product library never takes a device address from the environment
+            if (const char* st_env = getenv("DYGNN_CHAIN_STAMPS")) po.stamps = reinterpret_cast<unsigned long long*>(strtoull(st_env, nullptr, 0));
+#endif
             if (int rc = chain::launch_post(s, po)) return rc;
             if (direct) return DYGNN_OK;
             continue;

@@ -105,7 +105,10 @@ def train_sharded(step_fn: Callable[[int], torch.Tensor], parameters, optimizer,
     """One data-parallel epoch (train_link_prediction.py:188-257, sharded): `step_fn(batch_index)` runs forward + loss for one batch of this
     rank and returns the loss; every rank performs ceil(num_batches / world) optimizer steps (`shard_steps`) — zero_grad, backward where it
     has a batch, ONE gradient all-reduce, optimizer.step — so the ranks stay in lock-step when num_batches % world != 0.  Gradients are
-    averaged over the world (as torch DDP does).  Returns the losses of this rank's own batches."""
+    averaged over the world (as torch DDP does) — also in a step where some ranks are idle: the sum of the gradients of the ranks that had
+    a batch is still divided by the world size (DDP's join semantics), so the last step of an uneven epoch takes a smaller step; scale the
+    learning rate with the world size as for any data-parallel run (effective batch = world x 200).
+    Returns the losses of this rank's own batches; they are read back ONCE, after the loop — no host synchronisation per optimizer step."""
     params = [p for p in parameters]
     losses = []
     for i in shard_steps(num_batches, rank, world_size):
@@ -113,10 +116,10 @@ def train_sharded(step_fn: Callable[[int], torch.Tensor], parameters, optimizer,
         if i is not None:
             loss = step_fn(i)
             loss.backward()
-            losses.append(float(loss.detach()))
+            losses.append(loss.detach())
         allreduce_gradients(params, group)          # an idle rank contributes zeros
         optimizer.step()
-    return losses
+    return torch.stack([l.reshape(()) for l in losses]).tolist() if losses else []
 
 
 def allreduce_gradients(parameters: Iterable[torch.nn.Parameter], group=None) -> int:

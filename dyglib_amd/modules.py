@@ -69,8 +69,11 @@ class MergeLayer(nn.Module):
         self.act = nn.ReLU()
 
     def forward(self, input_1: torch.Tensor, input_2: torch.Tensor):
+        # the library's backward (dygnn_merge_layer_backward) holds the hidden layer in LDS: hidden % 4 == 0 and hidden <= 192 — any other
+        # link predictor takes the PyTorch ops in BOTH directions (a forward through the library would fail inside loss.backward())
         if (input_1.is_cuda and self.fc2.out_features == 1 and input_1.dim() == 2 and input_1.shape == input_2.shape and input_1.shape[1] % 4 == 0
-                and 2 * input_1.shape[1] == self.fc1.in_features and self.fc1.weight.is_cuda and self.fc1.weight.dtype == torch.float32):
+                and 2 * input_1.shape[1] == self.fc1.in_features and self.fc1.weight.is_cuda and self.fc1.weight.dtype == torch.float32
+                and self.fc1.out_features % 4 == 0 and self.fc1.out_features <= 192):
             return _MergeFunction.apply(input_1, input_2, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
         x = torch.cat([input_1, input_2], dim=1)
         return self.fc2(self.act(self.fc1(x)))

@@ -58,6 +58,28 @@ def test_gradients_match_oracle_autograd(name):
         close_scaled(got, ref, f"{name} grad {k}", label=f"gradients vs oracle autograd, {name} (worst tensor, scaled bar)")
 
 
+def test_four_layer_gradients_match_oracle_autograd():
+    """More than 16 weight-gradient problems in the one grouped launch (4 per encoder layer + 4 projections = 20 at four layers): the
+    launch's item code once held the problem index in 4 bits, which aliased problems 16..19 onto 0..3 — zero projection gradients and
+    doubled tiles elsewhere, silently.  The reference holds no four-layer fixture: torch autograd through the oracle is the bar."""
+    from dyglib_amd import synthetic as syn
+    c = dict(gc.build_case("hub_p4_l48"))
+    c["cfg"] = dict(c["cfg"], num_layers=4)
+    c["params"] = syn.make_dygformer_params(77, patch_size=c["cfg"]["patch_size"], num_layers=4)
+    model, _ = build_model(c)
+    G1, G2 = _loss_weights(c)
+    want, ws, wd = _oracle_grads(c, G1, G2)
+    model.eval()
+    s, t = model.compute_src_dst_node_temporal_embeddings(c["src"], c["dst"], c["times"])
+    for got, ref, side in ((s, ws, "src"), (t, wd, "dst")):
+        close(got.detach().cpu().numpy(), ref, f"train forward 4 layers {side} emb")
+    ((s * torch.from_numpy(G1).cuda()).sum() + (t * torch.from_numpy(G2).cuda()).sum()).backward()
+    for k, p in model.named_parameters():
+        got = p.grad.detach().cpu().numpy()
+        assert float(np.abs(want[k]).max()) > 0 and float(np.abs(got).max()) > 0, k            # no tensor's gradient went missing
+        close_scaled(got, want[k], f"4 layers grad {k}", label="gradients vs oracle autograd, 4 layers (worst tensor, scaled bar)")
+
+
 def test_train_mode_without_dropout_equals_eval_forward():
     c = gc.build_case("bip_p2_l64")
     model, _ = build_model(c)
@@ -207,6 +229,27 @@ def test_merge_layer_autograd_matches_the_cpu_module(n):
     close(bh.grad.cpu().numpy(), br.grad.numpy().astype(np.float32), f"merge d input_2 n={n}", label="MergeLayer input gradients")
     for (k, ph), (_, pr) in zip(hip.named_parameters(), ref.named_parameters()):
         close_scaled(ph.grad.cpu().numpy(), pr.grad.numpy().astype(np.float32), f"merge grad {k} n={n}", label="MergeLayer parameter gradients (scaled bar)")
+
+
+@pytest.mark.parametrize("hidden", [256, 170])
+def test_merge_layer_with_a_hidden_size_outside_the_library_range_trains_through_pytorch(hidden):
+    """The library's MergeLayer backward holds the hidden layer in LDS (hidden % 4 == 0, <= 192).  Any other link predictor must take the
+    PyTorch ops in both directions — a forward through the library would raise inside loss.backward()."""
+    from dyglib_amd import MergeLayer
+    torch.manual_seed(3)
+    ref = MergeLayer(172, 172, hidden, 1).double()
+    hip = MergeLayer(172, 172, hidden, 1)
+    hip.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    hip = hip.cuda()
+    a, b = torch.randn(33, 172), torch.randn(33, 172)
+    ar, br = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref(ar, br).sum().backward()
+    ah, bh = a.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    z = hip(ah, bh)
+    z.sum().backward()                                          # must not raise
+    close(ah.grad.cpu().numpy(), ar.grad.numpy().astype(np.float32), f"merge hidden={hidden} d input_1", label="MergeLayer (PyTorch path) input gradients")
+    for (k, ph), (_, pr) in zip(hip.named_parameters(), ref.named_parameters()):
+        close_scaled(ph.grad.cpu().numpy(), pr.grad.numpy().astype(np.float32), f"merge hidden={hidden} grad {k}", label="MergeLayer (PyTorch path) parameter gradients")
 
 
 @pytest.mark.parametrize("name", ["bip_p2_l64", "bip_p8_l512"])

@@ -3,6 +3,7 @@
 address of a device buffer of 16 uint64 per workgroup) over steps of bench.py's TGN workload.  Shares of the kernel's cycles (s_memtime
 runs at the shader clock here: the sum is ~63 k ticks for a 30-us kernel)."""
 import os, sys
+os.environ.setdefault("DYGNN_LIB_VARIANT", "stamps")      # the hook is compiled only into the stamps build (python -m dyglib_amd._build --variant=stamps)
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
