@@ -571,6 +571,27 @@ def bench_tgat(dev, steps: int = 64, warmup: int = 3, fuse_steps: int = 32, edge
                         "entries_per_step": {"reference": 2 * 2 * B * (1 + K + 1), "in_call_layout": total_entries / F, "computed": round(per_step, 1)},
                         "reference_formulation_equivalent_TFLOPs": round(179.4e9 / sec_step / 1e12, 1),
                         "note": "executed flops of the computed (node, time) entries (1.062 MFLOP each; duplicates of level 1 computed once)"}}
+    # the reference's best TGAT configuration on Reddit samples `uniform` (utils/load_configs.py:83-84): the draws are the sampler's numpy
+    # RandomState stream, replayed on the host (one library call per level: dygnn_mt19937_choice_rows_host), two calls per step like the
+    # reference (evaluate_models_utils.py:126-136).  Parity of this path: the reference's fixtures (tests/golden/tgat_rand_*, sampling_*).
+    usampler = get_neighbor_sampler(data, "uniform", seed=3, device=dev)
+    model.set_neighbor_sampler(usampler)
+    hs_, hd_, hn_, ht_ = host[0]
+    ustep = lambda j: (merge.link_probabilities(*model.compute_src_dst_node_temporal_embeddings(hs_[j * B:(j + 1) * B], hd_[j * B:(j + 1) * B], ht_[j * B:(j + 1) * B], num_neighbors=K)),
+                       merge.link_probabilities(*model.compute_src_dst_node_temporal_embeddings(hs_[j * B:(j + 1) * B], hn_[j * B:(j + 1) * B], ht_[j * B:(j + 1) * B], num_neighbors=K)))
+    nu = min(12, F)
+    with torch.no_grad():
+        ustep(0)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for j in range(nu):
+            ustep(j)
+        torch.cuda.synchronize(dev)
+    elu = (time.perf_counter() - t2) / nu
+    out["uniform"] = {"value": round(B / elu, 1), "unit": "edges/s", "ms_per_step": round(elu * 1e3, 3), "steps": nu,
+                      "what": "sample_neighbor_strategy='uniform' (the reference's best TGAT configuration on Reddit): RandomState draws replayed on the host, "
+                              "positive and negative call per step, PCIe-inclusive; parity by the reference fixtures tests/golden/tgat_rand_*.npz"}
+    model.set_neighbor_sampler(sampler)
     if cpu_budget_s > 0:
         from oracle import dygformer_oracle as orc, tgat_oracle as torc
         torch.set_num_threads(cpu_threads())

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported first: see module docstring)
 from . import _build
 
 DYGNN_MAX_LAYERS = 8
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -86,6 +86,7 @@ class DygformerTaps(C.Structure):
 SIGNATURES = {
     "dygnn_last_error": (C.c_char_p, []),
     "dygnn_abi_version": (C.c_int, []),
+    "dygnn_mt19937_choice_rows_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "dygnn_csr_build_host": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dygnn_find_neighbors_before": (C.c_int, [C.POINTER(Csr), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
@@ -125,6 +126,9 @@ SIGNATURES = {
     "dygnn_tgn_forward_step": (C.c_int, [C.POINTER(TgatConfig), C.POINTER(TgatWeights), C.POINTER(GruWeights), C.POINTER(Csr), C.c_void_p, C.c_void_p,
                                          C.POINTER(TgnState), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dygnn_tgn_forward_levels": (C.c_int, [C.POINTER(TgatConfig), C.POINTER(TgatWeights), C.POINTER(GruWeights), C.POINTER(TgatLevels), C.c_void_p, C.c_void_p,
+                                           C.POINTER(TgnState), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dygnn_dygformer_train_workspace_bytes": (C.c_size_t, [C.POINTER(DygformerConfig), C.c_int64]),
     "dygnn_dygformer_train_forward": (C.c_int, [C.POINTER(DygformerConfig), C.POINTER(DygformerWeights), C.POINTER(Csr), C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p,

@@ -31,7 +31,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" const char* dygnn_last_error(void) { return dygnn::g_last_error.c_str(); }
 
-extern "C" int dygnn_abi_version(void) { return 13; }
+extern "C" int dygnn_abi_version(void) { return 14; }
 
 extern "C" int dygnn_csr_build_host(int64_t num_edges, const int64_t* src, const int64_t* dst, const int64_t* eid,
                                     const double* ts, int64_t num_nodes, int64_t* indptr, int32_t* nbr_out,
@@ -80,5 +80,56 @@ extern "C" int dygnn_csr_build_host(int64_t num_edges, const int64_t* src, const
             nbr_out[a + i] = tn[perm[i]]; eid_out[a + i] = te[perm[i]]; ts_out[a + i] = tt[perm[i]];
         }
     }
+    return DYGNN_OK;
+}
+
+// ---- `uniform` neighbour sampling: the reference's draws, replayed on the host ------------------------------------------
+// utils/utils.py:186-188: `self.random_state.choice(a=len(history), size=k)` per query row, on numpy's LEGACY RandomState =
+// MT19937 + randint(0, n): every draw takes 32-bit outputs masked to the smallest 2^b - 1 >= n - 1 until one is <= n - 1 (rejection);
+// a row with one past interaction consumes nothing.  The caller (NeighborSampler._draw_host) moves the generator's key / position out of
+// and back into its numpy RandomState around the call, so the stream continues exactly where numpy's would: one library call per batch
+// instead of one Python call per row (the rows of a TGAT level: 10^3 .. 10^5 per batch).
+namespace {
+struct Mt { uint32_t* key; int pos; };
+inline void mt_refill(Mt& m) {
+    constexpr int N = 624, M = 397;
+    constexpr uint32_t A = 0x9908b0dfu, UP = 0x80000000u, LO = 0x7fffffffu;
+    uint32_t* k = m.key;
+    int i = 0;
+    for (; i < N - M; ++i) { const uint32_t y = (k[i] & UP) | (k[i + 1] & LO); k[i] = k[i + M] ^ (y >> 1) ^ ((y & 1u) ? A : 0u); }
+    for (; i < N - 1; ++i) { const uint32_t y = (k[i] & UP) | (k[i + 1] & LO); k[i] = k[i + (M - N)] ^ (y >> 1) ^ ((y & 1u) ? A : 0u); }
+    const uint32_t y = (k[N - 1] & UP) | (k[0] & LO);
+    k[N - 1] = k[M - 1] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+    m.pos = 0;
+}
+inline uint32_t mt_next(Mt& m) {
+    if (m.pos >= 624) mt_refill(m);
+    uint32_t y = m.key[m.pos++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+}  // namespace
+
+extern "C" int dygnn_mt19937_choice_rows_host(uint32_t* key, int32_t* pos, const int32_t* hist_len, int64_t n, int32_t k, int32_t* sampled) {
+    DYGNN_REQUIRE(key && pos && hist_len && sampled && n >= 0 && k > 0, "mt19937_choice_rows: bad arguments");
+    DYGNN_REQUIRE(*pos >= 0 && *pos <= 624, "mt19937_choice_rows: generator position %d outside [0, 624]", (int)*pos);
+    Mt m{key, *pos};
+    for (int64_t r = 0; r < n; ++r) {
+        int32_t* o = sampled + r * k;
+        const int32_t cnt = hist_len[r];
+        if (cnt <= 1) {                       // no history: the row is skipped (utils/utils.py:178); one entry: randint(0, 1) draws nothing
+            for (int32_t j = 0; j < k; ++j) o[j] = 0;
+            continue;
+        }
+        const uint32_t rng = (uint32_t)cnt - 1u;
+        uint32_t mask = rng;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        for (int32_t j = 0; j < k; ++j) {
+            uint32_t v;
+            do { v = mt_next(m) & mask; } while (v > rng);
+            o[j] = (int32_t)v;
+        }
+    }
+    *pos = m.pos;
     return DYGNN_OK;
 }

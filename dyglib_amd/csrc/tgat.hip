@@ -86,6 +86,18 @@ __global__ __launch_bounds__(256) void k_tgat_expand(const int64_t* __restrict__
     }
 }
 
+// TGN on PRE-SAMPLED levels (random sampling strategies): what k_tgat_expand's `tt` does while it writes level 0 — every level-0 slot names
+// itself owner of its node (slot code: level-1 entry q, neighbour column j, or k for the entry itself), the two list counters are zeroed
+__global__ void k_tgn_touch_levels(const int32_t* __restrict__ ids0, int64_t n1, int k, TgnTouch tt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2) tt.counts[i] = 0;
+    if (i >= n1 * (k + 1)) return;
+    const int32_t node = ids0[i];
+    if (node < 0 || node >= tt.N) return;
+    if (i < n1) tt.owner[node] = (int32_t)(i * (k + 1) + k);
+    else { const int64_t q = (i - n1) / k; tt.owner[node] = (int32_t)(q * (k + 1) + (i - n1 - q * k)); }
+}
+
 // the query-input rows alone, [n][Fn+Ft] = [h(self) | cos(b)]: one wave per row, four rows per workgroup, float4 copies (its predecessor, one
 // 256-thread workgroup per 1.1-KB row, ran a 119 k-row level at 1.3 TB/s: 163 us) (models/modules.py:150-157)
 __global__ __launch_bounds__(256) void k_tgat_qrows(const float* __restrict__ h_lower, const float* __restrict__ node_feat, const int32_t* __restrict__ lower_ids,
@@ -544,13 +556,13 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
                              const float* edge_feat, const int64_t* src, const int64_t* dst, const double* times, int64_t batch,
                              float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream,
                              const dygnn_tgat_levels* levels = nullptr, bool levels_in_workspace = false, bool expand_only = false,
-                             const TgnTouch* touch = nullptr, bool packed = false, bool times_per_root = false) {
+                             const TgnTouch* touch = nullptr, bool packed = false, bool times_per_root = false, bool presampled = false) {
     if (int rc = check_tgat(cfg)) return rc;
     DYGNN_REQUIRE(w && w->time_w && w->time_b, "tgat: null weights");
-    DYGNN_REQUIRE(levels || (csr && csr->indptr && csr->num_nodes >= 1), "tgat: bad csr");
+    DYGNN_REQUIRE(levels || levels_in_workspace || (csr && csr->indptr && csr->num_nodes >= 1), "tgat: bad csr");
     DYGNN_REQUIRE(batch >= 0 && node_feat && edge_feat, "tgat: bad arguments");
     if (batch == 0) return DYGNN_OK;
-    DYGNN_REQUIRE((levels || (src && dst && times)) && out_src && out_dst && workspace, "tgat: null pointer");
+    DYGNN_REQUIRE((levels || levels_in_workspace || (src && dst && times)) && out_src && out_dst && workspace, "tgat: null pointer");
     const TgatPlan p = make_tgat_plan(*cfg, batch);
     if (workspace_bytes < p.total) {
         set_error("tgat: workspace too small (%zu < %zu bytes)", workspace_bytes, p.total);
@@ -568,7 +580,7 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     // Distinct entries of level 1 are computed once (see k_dedup_insert): only when the library samples itself (`recent` is a function of
     // (node, time); pre-sampled random levels draw independently per entry) and the pair attention kernel, which knows the row map, applies.
-    const bool dedup = tgat_dedup_active(p, levels != nullptr);
+    const bool dedup = tgat_dedup_active(p, levels != nullptr || presampled);
 
     if (levels_in_workspace) {
         // the caller ran this function's own expansion on this workspace already (TGN: it needs the level-0 node set before the features exist)
@@ -836,7 +848,7 @@ extern "C" size_t dygnn_tgn_workspace_bytes(const dygnn_tgat_config* cfg, int64_
 static int tgn_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_gru_weights* gru, const dygnn_csr* csr,
                             const float* node_feat, const float* edge_feat, const dygnn_tgn_state* st, const int64_t* src, const int64_t* dst,
                             const double* times, const int64_t* edge_ids, int64_t batch, int64_t n_pos, float* out_src,
-                            float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
+                            float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream, const dygnn_tgat_levels* levels = nullptr) {
     const bool edges_are_positive = n_pos > 0;
     if (int rc = check_tgat(cfg)) return rc;
     DYGNN_REQUIRE(n_pos >= 0 && n_pos <= batch, "tgn: n_positive must be in [0, batch]");
@@ -864,15 +876,21 @@ static int tgn_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weigh
     char* wt = ws + p.tgat;
     const size_t wt_bytes = p.total - p.tgat;
     const TgnTouch touch{owner, count, N};
-    if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, wt, wt_bytes, stream, nullptr, false, true, &touch)) return rc;
     const TgatPlan tp = make_tgat_plan(*cfg, batch);
+    if (levels) {
+        // pre-sampled levels (`uniform` / `time_interval_aware`: the caller replayed the sampler's RandomState, MemoryModel.py:626-629): copied to
+        // where the expansion would have written them, then every level-0 slot names itself owner of its node
+        if (int rc = tgat_forward_impl(cfg, w, nullptr, feat0, edge_feat, nullptr, nullptr, nullptr, batch, out_src, out_dst, wt, wt_bytes, stream, levels, false, true)) return rc;
+        hipLaunchKernelGGL(k_tgn_touch_levels, dim3((unsigned)ceil_div(tp.n[0], 256)), dim3(256), 0, s, reinterpret_cast<const int32_t*>(wt + tp.ids[0]), tp.n[1], tp.k, touch);
+        DYGNN_LAUNCH_CHECK();
+    } else if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, wt, wt_bytes, stream, nullptr, false, true, &touch)) return rc;
     // 1. one launch: the owners list their nodes -- pending message: GRU rows; none: feat0 = memory + raw (MemoryModel.py:609) -- and the weights
     //    of the GRU and of the layers are packed into operand fragments (tgat_chain.h); then the updated memories of the listed nodes (the
     //    reference updates all nodes, MemoryModel.py:108-109): one launch, row count on the device
     DYGNN_REQUIRE(chain::fits(tp.Fn, tp.Ft, tp.Dkv, tp.H), "tgn: feature dims do not fit the row-block kernels");
     const chain::PackPlan pp = chain::plan_pack(tp.L, tp.Fn, tp.Ft, tp.Dkv, tp.H, Dm);
     float* pk = reinterpret_cast<float*>(wt + tp.pack);
-    const int32_t* live = tgat_dedup_active(tp, false) ? reinterpret_cast<const int32_t*>(wt + tp.dd_count) : nullptr;
+    const int32_t* live = tgat_dedup_active(tp, levels != nullptr) ? reinterpret_cast<const int32_t*>(wt + tp.dd_count) : nullptr;
     const chain::ListArgs la{reinterpret_cast<const int32_t*>(wt + tp.ids[0]), live, owner, st->has_msg, pendf, count, list, count2, list2, tp.n[1], N, tp.k};
     if (int rc = chain::pack(s, pp, tp.L, tp.Fn, tp.Ft, tp.Dkv, tp.H, w, gru, Dm, pk, &la)) return rc;
     const int64_t ub = N < tp.n[0] ? N : tp.n[0];              // the list cannot be longer than the level-0 set
@@ -880,7 +898,7 @@ static int tgn_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weigh
     if (int rc = chain::launch_gru(s, ga)) return rc;
     // 2. temporal graph attention over (memory + raw) features (GraphAttentionEmbedding, MemoryModel.py:548-664) on the levels built above
     if (int rc = tgat_forward_impl(cfg, w, csr, feat0, edge_feat, src, dst, times, batch, out_src, out_dst, wt, wt_bytes, stream, nullptr, true, false, nullptr,
-                                   true)) return rc;
+                                   true, false, levels != nullptr)) return rc;
     if (!edges_are_positive) return DYGNN_OK;
     // 3. persist the updated memories of the batch nodes and store their new raw messages (MemoryModel.py:142-161)
     hipLaunchKernelGGL(k_tgn_commit, dim3((unsigned)(2 * n_pos)), dim3(256), 0, s, src, dst, times, edge_ids, n_pos, Mnew, pendf, st->memory, st->last_update, edge_feat,
@@ -895,6 +913,20 @@ extern "C" int dygnn_tgn_forward(const dygnn_tgat_config* cfg, const dygnn_tgat_
                                  float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
     return tgn_forward_impl(cfg, w, gru, csr, node_feat, edge_feat, st, src, dst, times, edge_ids, batch, edges_are_positive ? batch : 0, out_src, out_dst,
                             workspace, workspace_bytes, stream);
+}
+
+// dygnn_tgn_forward_step on PRE-SAMPLED levels: the reference accepts any sampling strategy for TGN (MemoryModel.py:626-629); `uniform` and
+// `time_interval_aware` draw from the sampler's numpy RandomState, which the host mirror replays in the reference's order (one call on
+// [src ; dst], MemoryModel.py:104-131) and hands over as level arrays in dygnn_tgat_forward_levels' layout.  src / dst / times are still read:
+// by the commit of a positive call (messages, last-update times).
+extern "C" int dygnn_tgn_forward_levels(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_gru_weights* gru,
+                                        const dygnn_tgat_levels* levels, const float* node_feat, const float* edge_feat, const dygnn_tgn_state* st,
+                                        const int64_t* src, const int64_t* dst, const double* times, const int64_t* edge_ids, int64_t batch,
+                                        int64_t n_positive, float* out_src, float* out_dst, void* workspace, size_t workspace_bytes, dygnn_stream_t stream) {
+    DYGNN_REQUIRE(levels != nullptr, "tgn_forward_levels: levels is NULL");
+    DYGNN_REQUIRE(n_positive == 0 || (src && dst && times), "tgn_forward_levels: a positive call needs src / dst / times");
+    return tgn_forward_impl(cfg, w, gru, nullptr, node_feat, edge_feat, st, src, dst, times, edge_ids, batch, n_positive, out_src, out_dst, workspace,
+                            workspace_bytes, stream, levels);
 }
 
 extern "C" int dygnn_tgn_forward_step(const dygnn_tgat_config* cfg, const dygnn_tgat_weights* w, const dygnn_gru_weights* gru, const dygnn_csr* csr,

@@ -128,6 +128,13 @@ class MemoryModel(nn.Module):
         compute_src_dst_node_temporal_embeddings(neg..., edges_are_positive=False) followed by (...pos..., edges_are_positive=True)."""
         cat = lambda a, b: (torch.cat([a, b]) if isinstance(a, torch.Tensor) else np.concatenate([np.asarray(a), np.asarray(b)]))
         n_pos = len(src_node_ids)
+        if self.embedding_module.neighbor_sampler.sample_neighbor_strategy != "recent":
+            # random strategies draw per call: the reference's two calls in its order, negative first (evaluate_models_utils.py:85-107)
+            ns, nd = self.compute_src_dst_node_temporal_embeddings(neg_src_node_ids, neg_dst_node_ids, node_interact_times, None, edges_are_positive=False,
+                                                                   num_neighbors=num_neighbors)
+            ps, pd = self.compute_src_dst_node_temporal_embeddings(src_node_ids, dst_node_ids, node_interact_times, edge_ids, edges_are_positive=True,
+                                                                   num_neighbors=num_neighbors)
+            return ps, pd, ns, nd
         s, d = self.compute_src_dst_node_temporal_embeddings(cat(src_node_ids, neg_src_node_ids), cat(dst_node_ids, neg_dst_node_ids),
                                                              cat(node_interact_times, node_interact_times), edge_ids, edges_are_positive=True,
                                                              num_neighbors=num_neighbors, _n_positive=n_pos)
@@ -137,6 +144,8 @@ class MemoryModel(nn.Module):
         """compute_step_embeddings for a caller that already holds the step as ONE batch [positives ; negatives] (ids and times [2B], edge
         ids [B]): returns (src_emb, dst_emb) [2B, dim] as the library wrote them — rows 0 .. n_positive-1 are the positive call's, the rest the
         negative call's — so neither the inputs nor the link predictor's operands are concatenated on the device per step."""
+        if self.embedding_module.neighbor_sampler.sample_neighbor_strategy != "recent":
+            raise NotImplementedError("compute_step_embeddings_joint: `recent` sampling only (a random strategy draws per call: use compute_step_embeddings)")
         return self.compute_src_dst_node_temporal_embeddings(src_pos_neg, dst_pos_neg, times_pos_neg, edge_ids, edges_are_positive=True,
                                                              num_neighbors=num_neighbors, _n_positive=int(n_positive))
 
@@ -149,7 +158,9 @@ class MemoryModel(nn.Module):
             raise NotImplementedError("MemoryModel forward with autograd recording (training) is not built on the HIP path (SURVEY.md §8f-1): "
                                       "call it under torch.no_grad()")
         sampler = self.embedding_module.neighbor_sampler
-        sampler._require_recent()
+        random_strategy = sampler.sample_neighbor_strategy != "recent"
+        if random_strategy and _n_positive is not None:
+            raise NotImplementedError("a joint [positives ; negatives] step needs `recent` sampling (a random strategy draws per call)")
         dev = self.memory_bank.node_memories.device
         if dev.type != "cuda":
             raise _capi.DygnnError("dyglib_amd.MemoryModel runs on an MI355X only; there is no CPU fallback")
@@ -205,9 +216,59 @@ class MemoryModel(nn.Module):
         n_pos = (B if edges_are_positive else 0) if _n_positive is None else int(_n_positive)
         if eids is not None and eids.numel() < n_pos:
             raise AssertionError("edge_ids must cover the positive edges")
+        if random_strategy:
+            # MemoryModel.py:626-629 with `uniform` / `time_interval_aware`: the draws are replayed on the host in the reference's order and the
+            # library runs on the pre-sampled levels (dygnn_tgn_forward_levels)
+            h = lambda x: x.cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+            lv, keep = self._sample_levels_host(h(src_node_ids).astype(np.int64), h(dst_node_ids).astype(np.int64), h(node_interact_times).astype(np.float64),
+                                                int(num_neighbors), dev)
+            _capi.check(self._lib.dygnn_tgn_forward_levels(C.byref(cfg), C.byref(w), C.byref(gru), C.byref(lv), self.node_raw_features.data_ptr(),
+                                                           self.edge_raw_features.data_ptr(), C.byref(st), src.data_ptr(), dst.data_ptr(), tms.data_ptr(),
+                                                           eids.data_ptr() if eids is not None else None, B, n_pos, out_src.data_ptr(), out_dst.data_ptr(),
+                                                           ws.data_ptr(), ws.numel(), _capi.current_stream_ptr()))
+            torch.cuda.current_stream(dev).synchronize()          # `keep` (the level tensors) may be freed afterwards
+            return out_src, out_dst
         _capi.check(self._lib.dygnn_tgn_forward_step(C.byref(cfg), C.byref(w), C.byref(gru), sampler.csr.on_device(dev),
                                                      self.node_raw_features.data_ptr(), self.edge_raw_features.data_ptr(), C.byref(st),
                                                      src.data_ptr(), dst.data_ptr(), tms.data_ptr(), eids.data_ptr() if eids is not None else None,
                                                      B, n_pos, out_src.data_ptr(), out_dst.data_ptr(),
                                                      ws.data_ptr(), ws.numel(), _capi.current_stream_ptr()))
         return out_src, out_dst
+
+    # ---- random sampling strategies: the draws are replayed on the host in the reference's recursion order -------------------------------
+    def _sample_levels_host(self, src: np.ndarray, dst: np.ndarray, t: np.ndarray, k: int, dev):
+        """Level sets for dygnn_tgn_forward_levels.  The reference embeds [src ; dst] in ONE recursion (MemoryModel.py:104-131):
+        compute_node_temporal_embeddings(nodes, l) first recurses for the nodes themselves at layer l-1 (drawing THEIR neighbours, :596-600),
+        then draws the layer-l neighbours (:606-609), then recurses for those (:613-617).  Every draw consumes the sampler's RandomState."""
+        if self.num_layers not in (1, 2):
+            raise NotImplementedError("TGN with a random sampling strategy is built for num_layers 1 and 2")
+        smp = self.embedding_module.neighbor_sampler
+        L = self.num_layers
+        nodes, times = np.concatenate([src, dst]), np.concatenate([t, t])
+
+        def draw(n_, t_):
+            n, e, tn = smp.get_historical_neighbors(n_, t_, num_neighbors=k)               # host round trip, RandomState replay
+            return n, e, tn, (t_[:, None] - tn).astype(np.float32)                           # MemoryModel.py:623-626
+        ids, eid, dts = {L: nodes}, {}, {}
+        if L == 1:
+            top = draw(nodes, times)
+        else:
+            own = draw(nodes, times)                                   # neighbours of the nodes themselves, for their layer-1 embedding
+            top = draw(nodes, times)                                   # layer-2 neighbours
+            nbr = draw(top[0].reshape(-1), top[2].reshape(-1).astype(np.float64))           # neighbours of those, for THEIR layer-1 embedding
+            eid[1], dts[1] = np.concatenate([own[1], nbr[1]]), np.concatenate([own[3], nbr[3]])
+        eid[L], dts[L] = top[1], top[3]
+        ids[L - 1] = np.concatenate([nodes, top[0].reshape(-1)])
+        if L == 2:
+            ids[0] = np.concatenate([ids[1], own[0].reshape(-1), nbr[0].reshape(-1)])
+        lv, keep = _capi.TgatLevels(), []
+        for l in range(L + 1):
+            a = torch.from_numpy(np.ascontiguousarray(ids[l], dtype=np.int32)).to(dev)
+            keep.append(a)
+            lv.ids[l] = a.data_ptr()
+            if l >= 1:
+                b = torch.from_numpy(np.ascontiguousarray(eid[l], dtype=np.int32)).to(dev)
+                c = torch.from_numpy(np.ascontiguousarray(dts[l], dtype=np.float32)).to(dev)
+                keep += [b, c]
+                lv.nbr_eid[l], lv.nbr_dt[l] = b.data_ptr(), c.data_ptr()
+        return lv, keep

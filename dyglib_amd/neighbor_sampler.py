@@ -12,6 +12,9 @@ from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
+import ctypes as C
+import os
+
 import numpy as np
 import torch
 
@@ -90,9 +93,26 @@ class NeighborSampler:
     def _draw_host(self, node_ids_host: np.ndarray, hist_len_host: np.ndarray, k: int) -> np.ndarray:
         """The reference's per-row draw (utils/utils.py:176-199) replayed with numpy: returns sel [n,k] int32 =
         positions inside each node's row in FINAL order (after the argsort of the float32 times), -1 = no history."""
-        sel = np.full((len(node_ids_host), k), -1, dtype=np.int32)
         tia = self.sample_neighbor_strategy == "time_interval_aware"
         indptr, ts = self.csr.indptr, self.csr.ts
+        if not tia and self.seed is not None and os.environ.get("DYGNN_SAMPLER_PYTHON_DRAWS") != "1":
+            # `uniform` on a seeded sampler: ALL rows' draws in one library call on the RandomState's own MT19937 state
+            # (dygnn_mt19937_choice_rows_host = RandomState.choice(a=cnt, size=k) row by row), then the reference's per-row steps as array
+            # operations: float32 times of the drawn positions, argsort along the row (numpy's own argsort: the same tie order as the
+            # reference's per-row call, utils/utils.py:196), positions in that order.  tests/test_sampling_strategies.py pins it to the
+            # Python loop below and to the reference's fixtures.
+            nodes = np.ascontiguousarray(node_ids_host, dtype=np.int64)
+            cnt = np.ascontiguousarray(hist_len_host, dtype=np.int32)
+            st = self.random_state.get_state(legacy=True)
+            key, pos = np.ascontiguousarray(st[1], dtype=np.uint32).copy(), C.c_int32(int(st[2]))
+            sampled = np.empty((len(nodes), k), dtype=np.int32)
+            _capi.check(self._lib.dygnn_mt19937_choice_rows_host(key.ctypes.data, C.byref(pos), cnt.ctypes.data, len(nodes), k, sampled.ctypes.data))
+            self.random_state.set_state(("MT19937", key, int(pos.value), st[3], st[4]))
+            t32 = ts[indptr[nodes][:, None] + sampled].astype(np.float32)                   # utils/utils.py:192 (rows without history: any valid position)
+            sel = np.take_along_axis(sampled, t32.argsort(axis=1), axis=1)                   # utils/utils.py:196-199
+            sel[cnt <= 0] = -1
+            return np.ascontiguousarray(sel, dtype=np.int32)
+        sel = np.full((len(node_ids_host), k), -1, dtype=np.int32)
         rng = self.random_state if self.seed is not None else np.random
         for idx, (node, cnt) in enumerate(zip(node_ids_host.tolist(), hist_len_host.tolist())):
             if cnt <= 0:

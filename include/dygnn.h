@@ -65,6 +65,13 @@ int dygnn_csr_build_host(int64_t num_edges, const int64_t* src_host, const int64
                          const int64_t* eid_host, const double* ts_host, int64_t num_nodes,
                          int64_t* indptr_host, int32_t* nbr_host, int32_t* eid_out_host, double* ts_out_host);
 
+/* `uniform` neighbour sampling, host side (utils/utils.py:176-199): row r draws k positions in [0, hist_len[r]) exactly
+ * as `RandomState.choice(a=hist_len[r], size=k)` of numpy's legacy MT19937 generator does (masked rejection on 32-bit outputs; rows with
+ * hist_len <= 1 consume nothing and get zeros).  key[624] / *pos are the generator's state, taken from and written back to the sampler's
+ * numpy RandomState by the caller, so the stream stays numpy's.  Host pointers; no GPU work. */
+int dygnn_mt19937_choice_rows_host(uint32_t* key_host, int32_t* pos_host, const int32_t* hist_len_host, int64_t n, int32_t k,
+                                   int32_t* sampled_host);
+
 /* find_neighbors_before for n queries (utils/utils.py:130-147): hist_len[q] = i =
  * searchsorted(times[node], t, side='left') and end_pos[q] = indptr[node] + i (absolute CSR
  * index one past the last strictly-earlier interaction).  Either output may be NULL. */
@@ -302,6 +309,18 @@ int dygnn_tgn_forward_step(const dygnn_tgat_config* cfg_host, const dygnn_tgat_w
                            const int64_t* src, const int64_t* dst, const double* times, const int64_t* edge_ids /* [n_positive] */,
                            int64_t batch, int64_t n_positive, float* out_src, float* out_dst,
                            void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
+
+/* dygnn_tgn_forward_step on PRE-SAMPLED neighbour levels: the reference's TGN accepts any sample_neighbor_strategy
+ * (models/MemoryModel.py:626-629 calls the sampler it was given; utils/utils.py:176-199 for 'uniform' / 'time_interval_aware', whose
+ * draws consume the sampler's numpy RandomState in call order).  The host mirror replays those draws in the reference's order — ONE
+ * get_historical_neighbors call on [src ; dst] per layer of the recursion, MemoryModel.py:104-131, :596-640 — and hands the levels over
+ * in dygnn_tgat_levels' layout (batch = pairs; level L = [src ; dst]).  src / dst / times / edge_ids are read by the commit of a positive
+ * call only (n_positive > 0).  Same workspace size as dygnn_tgn_forward. */
+int dygnn_tgn_forward_levels(const dygnn_tgat_config* cfg_host, const dygnn_tgat_weights* w_host, const dygnn_gru_weights* gru_host,
+                             const dygnn_tgat_levels* levels_host, const float* node_feat, const float* edge_feat,
+                             const dygnn_tgn_state* state_host, const int64_t* src, const int64_t* dst, const double* times,
+                             const int64_t* edge_ids /* [n_positive] */, int64_t batch, int64_t n_positive, float* out_src, float* out_dst,
+                             void* workspace, size_t workspace_bytes, dygnn_stream_t stream);
 
 /* ---- training: train_link_prediction.py:229-257 on the HIP path ------------------------------------
  * dygnn_dygformer_train_forward = models/DyGFormer.py:68-194 in TRAIN mode: dropout (probability dropout_p) on the attention

@@ -227,6 +227,34 @@ def run_tgn_case(name: str) -> dict:
     return out
 
 
+def run_tgn_random_case(name: str) -> dict:
+    """run_tgn_case with the random sampling strategies (MemoryModel.py:626-629 calls whatever sampler it holds)"""
+    c = gc.build_tgn_case(name)
+    d, cfg = c["data"], c["tgn_cfg"]
+    ref_data = RefData(d.src_node_ids, d.dst_node_ids, d.node_interact_times, d.edge_ids, d.labels)
+    out = {}
+    for tag, (strategy, seed, tsf) in gc.SAMPLING_STRATEGIES.items():
+        sampler = ref_get_neighbor_sampler(ref_data, sample_neighbor_strategy=strategy, time_scaling_factor=tsf, seed=seed)
+        model = RefMemoryModel(c["node_feat"], c["edge_feat"], sampler, time_feat_dim=cfg["time_feat_dim"], model_name="TGN",
+                               num_layers=cfg["num_layers"], num_heads=cfg["num_heads"], dropout=0.1, device="cpu")
+        sd = model.state_dict()
+        for k, v in c["tgn_params"].items():
+            sd[k] = torch.from_numpy(v)
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        model.memory_bank.__init_memory_bank__()
+        with torch.no_grad():
+            for i, b in enumerate(c["tgn_batches"]):
+                ns, nd = model.compute_src_dst_node_temporal_embeddings(b["src"], b["neg"], b["t"], edge_ids=None, edges_are_positive=False,
+                                                                        num_neighbors=cfg["num_neighbors"])
+                ps, pd = model.compute_src_dst_node_temporal_embeddings(b["src"], b["dst"], b["t"], edge_ids=b["eid"], edges_are_positive=True,
+                                                                        num_neighbors=cfg["num_neighbors"])
+                out[f"{tag}_b{i}_neg_src"], out[f"{tag}_b{i}_neg_dst"], out[f"{tag}_b{i}_pos_src"], out[f"{tag}_b{i}_pos_dst"] = ns.numpy(), nd.numpy(), ps.numpy(), pd.numpy()
+        out[f"{tag}_final_memory"] = model.memory_bank.node_memories.data.numpy().copy()
+        out[f"{tag}_final_last_update"] = model.memory_bank.node_last_updated_times.data.numpy().copy()
+    return out
+
+
 def run_eval_case(name: str) -> dict:
     """the reference's evaluate_model_link_prediction (evaluate_models_utils.py:18-153) end to end on the CPU"""
     import contextlib, io
@@ -296,7 +324,7 @@ def run_metric_cases() -> dict:
 def main():
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(8)
-    names = sys.argv[1:] or (list(gc.CASES) + list(gc.TGAT_CASES) + list(gc.TGN_CASES) + ["sampling_" + n for n in gc.SAMPLING_CASES] + ["loader_toy"] + ["grads_" + n for n in gc.GRAD_CASES] + ["tgat_rand_" + n for n in gc.TGAT_RANDOM_CASES] + ["metrics"] + list(gc.EVAL_CASES))
+    names = sys.argv[1:] or (list(gc.CASES) + list(gc.TGAT_CASES) + list(gc.TGN_CASES) + ["sampling_" + n for n in gc.SAMPLING_CASES] + ["loader_toy"] + ["grads_" + n for n in gc.GRAD_CASES] + ["tgat_rand_" + n for n in gc.TGAT_RANDOM_CASES] + ["tgn_rand_" + n for n in gc.TGN_RANDOM_CASES] + ["metrics"] + list(gc.EVAL_CASES))
     for name in names:
         if name in gc.EVAL_CASES:
             np.savez_compressed(os.path.join(gc.GOLDEN_DIR, name + ".npz"), **run_eval_case(name))
@@ -305,6 +333,11 @@ def main():
         if name == "metrics":
             np.savez_compressed(os.path.join(gc.GOLDEN_DIR, "metrics.npz"), **run_metric_cases())
             print("metrics: written")
+            continue
+        if name.startswith("tgn_rand_"):
+            path = os.path.join(gc.GOLDEN_DIR, name + ".npz")
+            np.savez_compressed(path, **run_tgn_random_case(name[len("tgn_rand_"):]))
+            print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
             continue
         if name.startswith("tgat_rand_"):
             path = os.path.join(gc.GOLDEN_DIR, name + ".npz")

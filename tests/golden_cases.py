@@ -60,6 +60,10 @@ TGN_CASES = {
     "tgn_gen_l2_k4": dict(graph="gen_p1_l32", num_layers=2, num_neighbors=4, param_seed=302, batch=25, n_batches=5),
 }
 
+# fixtures tgn_rand_<case>.npz: the same chronological runs with the reference's MemoryModel('TGN') on a `uniform` / `time_interval_aware`
+# sampler (one sampler per strategy tag of SAMPLING_STRATEGIES; negative call, then positive call per batch), incl. the final memory bank
+TGN_RANDOM_CASES = ("tgn_bip_l1_k10", "tgn_gen_l2_k4")
+
 TAP_ROWS = 3          # intermediates are stored for the first TAP_ROWS rows only
 SAMPLER_KS = (1, 10, 20)
 

@@ -216,6 +216,30 @@ def test_hip_other_feature_dims_against_oracle(form, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,heads", [(24, 2), (12, 4), (24, 4)])
+def test_hip_general_attention_kernels_against_oracle(k, heads):
+    """Configurations outside the two-waves-per-node attention kernel (k <= 20, <= 2 heads): more than 20 neighbours take k_tgat_attn_lin<0>
+    (row slots in LDS), more than two heads k_tgat_attn_lin<20> — the reference accepts any num_neighbors / num_heads
+    (models/TGAT.py:14-16, models/modules.py:99-135).  No reference fixture holds these shapes: the oracle is the bar."""
+    from dyglib_amd import TGAT, get_neighbor_sampler
+    data, nf, ef = syn.make_bipartite_graph(400, 50, 20000, seed=37)
+    nf[1:] = np.random.RandomState(5).standard_normal(nf[1:].shape).astype(np.float32) * 0.5
+    params = syn.make_tgat_params(14)
+    sampler = get_neighbor_sampler(data, "recent", seed=1, device="cuda:0")
+    m = TGAT(nf, ef, sampler, 100, num_layers=2, num_heads=heads, dropout=0.1, device="cuda:0")
+    m.load_state_dict({kk: torch.from_numpy(v) for kk, v in params.items()})
+    m = m.to("cuda:0").eval()
+    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    idx = np.concatenate([np.arange(3), np.arange(data.num_interactions - 120, data.num_interactions)])      # incl. nodes without history
+    src, dst, t = data.src_node_ids[idx], data.dst_node_ids[idx], data.node_interact_times[idx]
+    os_, od = torc.tgat_forward(params, nf, ef, adj, src, dst, t, 2, k, heads)
+    with torch.no_grad():
+        gs, gd = m.compute_src_dst_node_temporal_embeddings(src, dst, t, num_neighbors=k)
+    close(gs.cpu().numpy(), os_.numpy(), f"general attention k={k} heads={heads} src")
+    close(gd.cpu().numpy(), od.numpy(), f"general attention k={k} heads={heads} dst")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B", [200, 37])
 def test_hip_step_embeddings_equal_the_two_calls(B):
     """TGAT.compute_step_embeddings (dygnn_tgat_forward_roots: [sources ; destinations ; negative destinations] as one call, every root with
