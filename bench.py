@@ -283,10 +283,11 @@ def dygformer_roofline(wk: DygformerWorkload, res: dict, impl: int) -> dict:
     traffic, src = None, None
     try:
         import glob
-        tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))[-1]
-        tj = json.load(open(tf))
-        if wk.name == tj.get("workload", "wikipedia") and impl in (0, 3):
-            traffic, src = tj["hbm_bytes_per_pair"] * pairs, os.path.relpath(tf, ROOT)
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):       # the latest round's file of THIS workload
+            tj = json.load(open(tf))
+            if wk.name == tj.get("workload", "wikipedia") and impl in (0, 3):
+                traffic, src = tj["hbm_bytes_per_pair"] * pairs, os.path.relpath(tf, ROOT)
+                break
     except Exception:
         pass
     kern = {1: "generic multi-kernel path"}.get(impl, "k_dygformer_fused3<%d>" % (4 if 2 * ((L + P - 1) // P) <= 64 else 8))

@@ -4,7 +4,7 @@
 # The profiled command is the driver's: bench.py --steps 20 --warmup 5 (CPU legs and secondary workloads off).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/pmc
+OUT=${PMC_OUT:-$ROOT/gpurun_out/pmc}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
