@@ -31,6 +31,9 @@
 // opposite ends): 1.3-1.6 % SLOWER in every arrangement, the two waves of a SIMD already run the block one after the other (the older or
 // prioritised wave takes nearly every matrix-pipe slot), so one GELU of the two is hidden as it is; a static s_setprio 1 for waves 4-7: +-0.2 %;
 // stage barriers every 13 instead of 26 fragments in the FFN with the next group's fragments read before the barrier: slower (twice the barriers).
+#ifndef F3_XBAR
+#define F3_XBAR 0      // 1: the FFN's W1 blocks (2: W2 blocks too) start on fragments read across the stage barrier in front of them.  Measured and
+#endif                 // NOT kept (round 3, tools/ab_fused3.py, 32 steps per launch): 1 = -0.3 %, 2 = -2.7 % (16 more live VGPRs spill)
 #ifndef F3_KSKIP
 #define F3_KSKIP 1
 #endif
@@ -378,11 +381,16 @@ __device__ __forceinline__ void gelu_tiles(f4 (&t)[2]) {
     }
 }
 // First product: h[2] (two 16-wide hidden tiles) = b1 + W1 . LN(x); 13 k-chunks of two fragments [k-chunk][tile] read one chunk ahead.
-__device__ __forceinline__ void ffn_w1(f4 (&h)[2], const f4 (&xn)[kNT], const float xk0, const float xk1, const float* abuf, const float* b1p, const int g) {
+// pre != nullptr: the block's first two fragments were read by the caller BEFORE the stage barrier in front of the block (legal: a block's
+// fragments were made visible by the barrier one block earlier; the barrier in front of it only frees the ring half behind it) — the block
+// then starts on operands that are already in registers instead of exposing an LDS round trip to both waves of the SIMD at once
+__device__ __forceinline__ void ffn_w1(f4 (&h)[2], const f4 (&xn)[kNT], const float xk0, const float xk1, const float* abuf, const float* b1p, const int g,
+                                       const f4* pre = nullptr) {
     if (b1p != nullptr) { h[0] = lds4(b1p + 4 * g); h[1] = lds4(b1p + 16 + 4 * g); }
     else { h[0] = zero4(); h[1] = zero4(); }
     f4 sa[2][2];
-    sa[0][0] = lds4(abuf); sa[0][1] = lds4(abuf + kFrag);
+    if (pre) { sa[0][0] = pre[0]; sa[0][1] = pre[1]; }
+    else { sa[0][0] = lds4(abuf); sa[0][1] = lds4(abuf + kFrag); }
 #pragma unroll
     for (int kc = 0; kc < kKC; ++kc) {
         const int cur = kc & 1;
@@ -397,10 +405,10 @@ __device__ __forceinline__ void ffn_w1(f4 (&h)[2], const f4 (&xn)[kNT], const fl
 }
 // Second product: acc (13 model-dim tiles) += W2[:, the two hidden tiles] . h; fragments [tile u][n-tile i] in sub-groups (4,3,3,3)
 // read one sub-group ahead
-__device__ __forceinline__ void ffn_w2(f4 (&acc)[kNT], const f4 (&h)[2], const float* bbuf) {
+__device__ __forceinline__ void ffn_w2(f4 (&acc)[kNT], const f4 (&h)[2], const float* bbuf, const f4* pre = nullptr) {
     f4 fs[2][4];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) fs[0][v] = lds4(bbuf + (size_t)v * kFrag);
+    for (int v = 0; v < 4; ++v) fs[0][v] = pre ? pre[v] : lds4(bbuf + (size_t)v * kFrag);
 #pragma unroll
     for (int gi = 0; gi < 8; ++gi) {
         const int u = gi >> 2, q = gi & 3;
@@ -1185,11 +1193,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_dygformer_fused3(c
         TACC(T_LN);
         ws.align26();
         // W1(p) | W2(p) per step; W2 accumulates straight into the residual registers (no separate FFN accumulator: 52 VGPRs fewer)
+        constexpr bool XB = F3_XBAR && !TR;      // (the training forward has no registers to spare)
+        f4 pre1[2];                      // first fragments of the next W1 block, read across the stage barrier in front of it
+        if (XB && active) { pre1[0] = lds4(ringl + ws.pos * kFrag); pre1[1] = lds4(ringl + (ws.pos + 1) * kFrag); }
 #pragma unroll 1
         for (int p = 0; p < 25; ++p) {
             f4 h[2];
             if (active) {
-                ffn_w1(h, xn, xk0, xk1, ringl + ws.pos * kFrag, b1s + 32 * p, g);
+                ffn_w1(h, xn, xk0, xk1, ringl + ws.pos * kFrag, b1s + 32 * p, g, XB ? pre1 : nullptr);
                 TACC(T_F_W1);
                 if constexpr (TR) {
                     if (tokv) {
@@ -1210,9 +1221,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_dygformer_fused3(c
                 }
                 TACC(T_F_GELU);
             }
+            f4 pre2[4];                  // first fragments of this step's W2 block (blocks sit at ring positions 0 / 26)
+            if (XB && F3_XBAR > 1 && active) {
+                const float* nb = ringl + (ws.pos == 0 ? 26 : 0) * kFrag;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) pre2[v] = lds4(nb + (size_t)v * kFrag);
+            }
             ws.advance(26, (TR && active) ? 4 : 0);      // training: the four hpre / hact stores of this step stay in flight through the W2 block
             TACC(T_F_ADV1);
-            if (active) ffn_w2(f2, h, ringl + ws.pos * kFrag);
+            if (active) {
+                ffn_w2(f2, h, ringl + ws.pos * kFrag, (XB && F3_XBAR > 1) ? pre2 : nullptr);
+                if (XB && p + 1 < 25) {
+                    const float* nb = ringl + (ws.pos == 0 ? 26 : 0) * kFrag;       // the W1 block of the next step
+                    pre1[0] = lds4(nb); pre1[1] = lds4(nb + kFrag);
+                }
+            }
             TACC(T_F_W2);
             ws.advance(26);
             TACC(T_F_ADV2);
