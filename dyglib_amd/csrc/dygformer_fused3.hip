@@ -47,7 +47,16 @@ using i4 = __attribute__((ext_vector_type(4))) int;
 constexpr int kD = 200, kDP = 208, kNT = 13, kKC = 13, kHD = 100, kHid = 800, kC = 50;
 constexpr int kFrag = 256;            // floats per 16x16 fragment
 constexpr int kRing = 52;             // LDS ring, fragments
-constexpr int kStage = 13;            // DMA / barrier granularity, fragments
+// F3_STAGE = 26 (two stages of 26 fragments: half the stage barriers) measured +1.25 % at L = 64, +0.8 % at L = 512 (round 3, tools/ab_fused3.py) and
+// NOT kept: with two stages the fragments a step reads ahead ACROSS the barrier that ends a stage belong to a stage whose DMAs that very
+// barrier publishes (with four stages the barrier one stage earlier did) — a read-ahead that is legal only with three stages in flight;
+// re-reading after the barrier costs what the halved barriers save.
+#ifndef F3_STAGE
+#define F3_STAGE 13
+#endif
+constexpr int kStage = F3_STAGE;      // DMA / barrier granularity, fragments: the ring holds kRing / kStage stages
+constexpr int kNStage = kRing / kStage;
+static_assert(kStage * kNStage == kRing && kNStage >= 2, "the ring is a whole number (>= 2) of stages");
 constexpr int kTokWG = 128;           // tokens per workgroup
 constexpr int kKV = 100;              // K/V row stride (floats): 4*25 -> conflict-free b128 row reads and b32 column reads
 constexpr int kLdsK = 0;
@@ -247,9 +256,9 @@ struct WStream {
     __device__ __forceinline__ void issue(int s) {
         if (s < nstages) {
             const float* srcp = gsrc + (size_t)s * (kStage * kFrag);
-            const int dst = ring + (s & 3) * (kStage * kFrag);
+            const int dst = ring + (s % kNStage) * (kStage * kFrag);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < (kStage + 3) / 4; ++u) {      // nw >= 4 waves split the stage's fragments
                 const int f = wave + u * nw;
                 if (f < kStage) dma_frag(srcp + f * kFrag, dst + f * kFrag);
             }
@@ -257,9 +266,9 @@ struct WStream {
     }
     __device__ __forceinline__ void open(const float* stream, int ring_, int lane, int wave_, int nstages_, int nw_ = 8) {
         gsrc = stream + lane * 4; ring = ring_; wave = wave_; nstages = nstages_; nw = nw_;
-        pos = 0; instage = 0; issued = 4;
+        pos = 0; instage = 0; issued = kNStage;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) issue(s);
+        for (int s = 0; s < kNStage; ++s) issue(s);
     }
     // n fragments consumed (or skipped).  Crossing a stage boundary: wait for own DMAs, barrier (every wave is done with
     // the finished stage, every stage issued before is now visible), then refill the freed ring quarter.
