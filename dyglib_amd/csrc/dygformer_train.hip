@@ -49,6 +49,7 @@ struct MM {
     float* colsum;          // transA products only: colsum[m] += sum_k op(A)[m][k] (the bias gradient next to a weight gradient), or null
     const int32_t* m_dev;   // optional device-side row count (<= M): workgroups whose rows all lie beyond it exit at once
     int vecC;               // C rows may be written as aligned float4 (pointer, ldc and batch strides multiples of 4 floats)
+    const int32_t* a_rows;  // optional (k-contiguous A, LDS-DMA kernel only): row m of op(A) is A[a_rows[m]] — the product gathers its rows itself
 };
 
 __global__ __launch_bounds__(256) void k_mm(const MM p) {
@@ -292,13 +293,22 @@ __global__ __launch_bounds__(256) void k_mm_dma(const MM p) {
     const int rA = KA ? (lane & 15) : 4 * (lane & 3), kA = KA ? 4 * (lane >> 4) : 4 * ((lane >> 2) & 3) + (lane >> 4);
     const int rB = KB ? (lane & 15) : 4 * (lane & 3), kB = KB ? 4 * (lane >> 4) : 4 * ((lane >> 2) & 3) + (lane >> 4);
     const int nsteps = (kend - kbeg + 15) >> 4;
+    // rows of op(A) this lane loads (k-contiguous A): with a row table the product gathers them (rows beyond the live count read zeros: the
+    // table's entries there are not written)
+    int64_t arow[WM / 2];
+#pragma unroll
+    for (int u = 0; u < WM / 2; ++u) {
+        const int r = m0 + 16 * (wave + 4 * u) + rA;
+        const int mlim = (p.a_rows && p.m_dev) ? (*p.m_dev < p.M ? *p.m_dev : p.M) : p.M;
+        arow[u] = r < mlim ? ((KA && p.a_rows) ? (int64_t)p.a_rows[r] : (int64_t)r) : -1;
+    }
     auto issue = [&](int t) {                 // k-step t -> ring slot t % NS (beyond the last step: zeros, which keeps vmcnt uniform)
         const int k0 = kbeg + 16 * t;
         float* slot = ring + (t % NS) * STAGE;
 #pragma unroll
         for (int u = 0; u < WM / 2; ++u) {
             const int blk = wave + 4 * u, r = m0 + 16 * blk + rA;
-            const float* src = (t < nsteps && r < p.M && k0 + kA < kend) ? (KA ? A + (size_t)r * p.lda + k0 + kA : A + (size_t)(k0 + kA) * p.lda + r) : g_zero_page;
+            const float* src = (t < nsteps && arow[u] >= 0 && k0 + kA < kend) ? (KA ? A + (size_t)arow[u] * p.lda + k0 + kA : A + (size_t)(k0 + kA) * p.lda + r) : g_zero_page;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(slot + 256 * blk), 16, 0, 0);
         }
 #pragma unroll
@@ -424,10 +434,11 @@ static void launch_mm_dma(hipStream_t s, const MM& p, bool tA, bool tB, int batc
 static int colsum(hipStream_t s, const float* A, int lda, int64_t M, int N, float* out, bool accumulate = false);
 
 int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb, bool tB, float* C, int ldc, int M, int N, int K, const float* bias, float alpha,
-       float beta, int batch, int H, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, bool relu, bool c_is_zero, float* colsum_out, const int32_t* m_dev, bool a_kpad) {
+       float beta, int batch, int H, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, bool relu, bool c_is_zero, float* colsum_out, const int32_t* m_dev, bool a_kpad,
+       const int32_t* a_rows) {
     if (M <= 0 || N <= 0 || batch <= 0) return DYGNN_OK;
     MM p{A, B, C, bias, M, N, K, lda, ldb, ldc, tA ? 1 : 0, tB ? 1 : 0, alpha, beta, H, sAb, sAh, sBb, sBh, sCb, sCh, relu ? 1 : 0, 1, K, nullptr, m_dev,
-         ((reinterpret_cast<uintptr_t>(C) & 15) == 0 && ldc % 4 == 0 && sCb % 4 == 0 && sCh % 4 == 0) ? 1 : 0};
+         ((reinterpret_cast<uintptr_t>(C) & 15) == 0 && ldc % 4 == 0 && sCb % 4 == 0 && sCh % 4 == 0) ? 1 : 0, a_rows};
     if (colsum_out) {                 // rides along inside the 64-row-tile kernel; anything else gets the stand-alone reduction
         if (tA && batch == 1 && M >= 48 && N >= 48) p.colsum = colsum_out;
         else if (int rc = colsum(s, A, lda, K, M, colsum_out)) return rc;
@@ -461,6 +472,7 @@ int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb,
             DYGNN_LAUNCH_CHECK();
             return DYGNN_OK;
         }
+        if (a_rows) { set_error("mm: a row table needs the LDS-DMA kernel (aligned k-contiguous operands, K %% 4 == 0)"); return DYGNN_E_UNSUPPORTED; }
         const double w64 = (double)(ceil_div(N, 64) * 64) / N, w128 = (double)(ceil_div(N, 128) * 128) / N;
         if (N <= 64 || w64 * 0.95 < w128)
             hipLaunchKernelGGL((k_mm_big<2, 2>), dim3((unsigned)ceil_div(M, 64), (unsigned)ceil_div(N, 64), (unsigned)batch), dim3(256), 0, s, p, vecA, vecB);
@@ -469,6 +481,7 @@ int mm(hipStream_t s, const float* A, int lda, bool tA, const float* B, int ldb,
         DYGNN_LAUNCH_CHECK();
         return DYGNN_OK;
     }
+    if (a_rows) { set_error("mm: a row table needs at least 48 rows and columns"); return DYGNN_E_UNSUPPORTED; }
     hipLaunchKernelGGL(k_mm, dim3((unsigned)ceil_div(M, 64), (unsigned)ceil_div(N, 64), (unsigned)batch), dim3(256), 0, s, p);
     DYGNN_LAUNCH_CHECK();
     return DYGNN_OK;

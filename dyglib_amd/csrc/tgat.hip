@@ -119,7 +119,8 @@ using attn::cos_time_t;
 // Transposed product: accumulator tile = C^T[n = 4g+r][m = c]  ->  float4 store at C[m][n0 + 4g].
 template <bool RELU>
 __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
-                                                   float* __restrict__ C, int64_t M, int N, int K, int ldc) {
+                                                   float* __restrict__ C, int64_t M, int N, int K, int ldc, int ldw = 0) {
+    if (ldw == 0) ldw = K;                   // row stride of W (a product over the first K columns of wider rows passes it)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ A, co
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = n0 + 16 * i + c;
-            a[i] = (n < N && kk < K) ? *reinterpret_cast<const f4*>(W + (size_t)n * K + kk) : f4{0.f, 0.f, 0.f, 0.f};
+            a[i] = (n < N && kk < K) ? *reinterpret_cast<const f4*>(W + (size_t)n * ldw + kk) : f4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -352,9 +353,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         reinterpret_cast<float*>(smem), z + (size_t)i * H * Dkv, Dkv);
 }
 
+// The query input of a node is [h(node) | timeenc(0)] (models/TGAT.py:84, models/modules.py:150-157) and timeenc(0) = cos(b) is the SAME vector
+// for every row: q = W_q [h | cos(b)] = W_q[:, :Fn] h + W_q[:, Fn:] cos(b).  The second term is a constant of the call (cq, the bias of the
+// product over the Fn feature columns, which gathers its rows itself: no [n][Fn + Ft] query-input matrix is written or read), and the
+// residual branch of the layer (models/modules.py:196-199) rebuilds [h | cos(b)] from the feature row and ct = cos(b).
+__global__ void k_tgat_const_q(const float* __restrict__ Wq, const float* __restrict__ tw, const float* __restrict__ tb, int Dq, int Fn, int Ft,
+                               float* __restrict__ cq, float* __restrict__ ct) {
+    extern __shared__ float c_lds[];
+    for (int f = threadIdx.x; f < Ft; f += blockDim.x) { const float v = cosf(fmaf(0.0f, tw[f], tb[f])); c_lds[f] = v; ct[f] = v; }
+    __syncthreads();
+    for (int j = threadIdx.x; j < Dq; j += blockDim.x) {
+        float a = 0.f;
+        for (int f = 0; f < Ft; ++f) a = fmaf(Wq[(size_t)j * Dq + Fn + f], c_lds[f], a);
+        cq[j] = a;
+    }
+}
+
 // y = LayerNorm(fc_out + residual) (models/modules.py:196-199), written into the first Dq columns of the MergeLayer input
-// row [Dq + Fn]; the raw node features fill the rest (models/TGAT.py:134, models/modules.py:64)
-__global__ __launch_bounds__(256) void k_tgat_post(const float* __restrict__ fc_out, const float* __restrict__ q_in, const float* __restrict__ gamma,
+// row [Dq + Fn]; the raw node features fill the rest (models/TGAT.py:134, models/modules.py:64).  residual = [h(node) | cos(b)]: h from the
+// layer below (h_lower, through the row map of a de-duplicated level) or, for layer 1, the raw feature row itself
+__global__ __launch_bounds__(256) void k_tgat_post(const float* __restrict__ fc_out, const float* __restrict__ h_lower, const int32_t* __restrict__ lower_map,
+                                                     const float* __restrict__ ct, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const float* __restrict__ node_feat,
                                                      const int32_t* __restrict__ lower_ids, int64_t n, int Dq, int Fn, float* __restrict__ merge_in,
                                                      const int32_t* __restrict__ n_live) {
@@ -366,12 +385,14 @@ __global__ __launch_bounds__(256) void k_tgat_post(const float* __restrict__ fc_
     constexpr int NV = 5;
     float x[NV];
     const float* raw = node_feat + (size_t)lower_ids[i] * Fn;
+    const float* hrow = h_lower ? h_lower + (lower_map ? (int64_t)lower_map[i] : i) * Fn : raw;
     float rv[NV];
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         const int f = lane + kWave * u;
-        x[u] = f < Dq ? fc_out[i * Dq + f] + q_in[i * Dq + f] : 0.f;
         rv[u] = f < Fn ? raw[f] : 0.f;
+        const float res = f < Fn ? (h_lower ? hrow[f] : rv[u]) : (f < Dq ? ct[f - Fn] : 0.f);
+        x[u] = f < Dq ? fc_out[i * Dq + f] + res : 0.f;
     }
     float s = 0.f;
 #pragma unroll
@@ -465,7 +486,7 @@ struct TgatPlan {
     int64_t n[DYGNN_MAX_LAYERS + 1];       // level sizes: n[L] = 2B, n[l-1] = n[l] * (1 + k)
     // byte offsets
     size_t ids[DYGNN_MAX_LAYERS + 1], times[DYGNN_MAX_LAYERS + 1], eid[DYGNN_MAX_LAYERS + 1], dt[DYGNN_MAX_LAYERS + 1], h[DYGNN_MAX_LAYERS + 1];
-    size_t q_in, q, att, fc, merge_in, hid, qk, z, pack, total;
+    size_t q_in, q, att, fc, merge_in, hid, qk, z, pack, cq, total;
     // de-duplication of level L-1 (two-layer models, recent sampling): hash slots, representative / compact index / map per entry, compact level
     size_t dd_slots, dd_canon, dd_cidx, dd_map, dd_count, dd_ids, dd_times;
     uint32_t dd_cap;
@@ -495,6 +516,7 @@ static TgatPlan make_tgat_plan(const dygnn_tgat_config& c, int64_t B) {
     p.fc = take((size_t)nmax * p.Dq * sizeof(float));
     p.merge_in = take((size_t)nmax * (p.Dq + p.Fn) * sizeof(float));
     p.hid = take((size_t)nmax * p.Fn * sizeof(float));
+    p.cq = take((size_t)(p.L > 0 ? p.L : 1) * (p.Dq + p.Ft) * sizeof(float));      // per layer: the query's constant term [Dq] | cos(b) [Ft]
     if (p.L == 2) {
         p.dd_cap = 1024;
         while ((int64_t)p.dd_cap < 2 * p.n[1]) p.dd_cap <<= 1;
@@ -647,16 +669,28 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
         // the top level is [src rows ; dst rows]: when the caller's two outputs are one [2B, Fn] block it is written in place
         const bool direct = l == p.L && out_dst == out_src + (size_t)batch * p.Fn;
         float* h_out = direct ? out_src : F32(p.h[l]);
+        float* cq = F32(p.cq) + (size_t)(l - 1) * (p.Dq + p.Ft);
+        float* ct = cq + p.Dq;
         if (chain) {
             // q_in -> q -> W_k^T q inside one workgroup per 16 / 32 rows (tgat_chain.hip): intermediates stay in LDS
             chain::PreArgs pa{h_lower, node_feat, I32(p.ids[l - 1]), lmap, nl, w->time_w, w->time_b, F32(p.pack), pp.layer[l - 1].q, pp.layer[l - 1].k, F32(p.qk), n,
                               p.Fn, p.Ft, p.Dkv, p.H};
             if (int rc = chain::launch_pre(s, pa)) return rc;
         } else {
-        hipLaunchKernelGGL(k_tgat_qrows, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, s, h_lower, node_feat, I32(p.ids[l - 1]), w->time_w, w->time_b, n, p.Fn, p.Ft,
-                           F32(p.q_in), nl, lmap);     // query rows
+        // q = W_q[:, :Fn] h + cq (see k_tgat_const_q): the product gathers the feature rows itself
+        hipLaunchKernelGGL(k_tgat_const_q, dim3(1), dim3(256), (size_t)p.Ft * sizeof(float), s, Lw.query_w, w->time_w, w->time_b, p.Dq, p.Fn, p.Ft, cq, ct);
         DYGNN_LAUNCH_CHECK();
-        if (int rc = gemm_nt<false>(F32(p.q_in), Lw.query_w, nullptr, F32(p.q), n, p.Dq, p.Dq, p.Dq, s, nl)) return rc;
+        if (n >= 48) {
+            if (int rc = train::mm(s, h_lower ? h_lower : node_feat, p.Fn, false, Lw.query_w, p.Dq, true, F32(p.q), p.Dq, (int)n, p.Dq, p.Fn, cq, 1.f, 0.f, 1, 1, 0, 0, 0, 0,
+                                   0, 0, false, false, nullptr, nl, false, h_lower ? lmap : I32(p.ids[l - 1]))) return rc;
+        } else {      // a handful of rows: the feature rows are staged ([n][Fn], Ft = 0: no time columns), then the small-M kernel
+            hipLaunchKernelGGL(k_tgat_qrows, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, s, h_lower, node_feat, I32(p.ids[l - 1]), w->time_w, w->time_b, n, p.Fn, 0,
+                               F32(p.q_in), nl, lmap);
+            DYGNN_LAUNCH_CHECK();
+            hipLaunchKernelGGL((k_gemm_nt<false>), dim3((unsigned)ceil_div(n, 256), (unsigned)ceil_div(p.Dq, 64)), dim3(256), 0, s, F32(p.q_in), Lw.query_w, cq, F32(p.q), n,
+                               p.Dq, p.Fn, p.Dq, p.Dq);
+            DYGNN_LAUNCH_CHECK();
+        }
         // qk[i][h] = W_k,h^T q_ih : per head [n][hd] x [hd][Dkv] (rows h*hd .. of key_w), one batched launch over the heads
         if (int rc = train::mm(s, F32(p.q), p.Dq, false, Lw.key_w, p.Dkv, false, F32(p.qk), p.H * p.Dkv, (int)n, p.Dkv, p.hd, nullptr, 1.f, 0.f, p.H, p.H, 0, p.hd,
                                0, (int64_t)p.hd * p.Dkv, 0, p.Dkv, false, false, nullptr, nl)) return rc;
@@ -702,7 +736,7 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
         if (int rc = train::mm(s, F32(p.z), p.H * p.Dkv, false, Lw.value_w, p.Dkv, true, F32(p.att), p.Dq, (int)n, p.hd, p.Dkv, nullptr, 1.f, 0.f, p.H, p.H, 0, p.Dkv,
                                0, (int64_t)p.hd * p.Dkv, 0, p.hd, false, false, nullptr, nl)) return rc;
         if (int rc = gemm_nt<false>(F32(p.att), Lw.res_w, Lw.res_b, F32(p.fc), n, p.Dq, p.Dq, p.Dq, s, nl)) return rc;
-        hipLaunchKernelGGL(k_tgat_post, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, s, F32(p.fc), F32(p.q_in), Lw.ln_w, Lw.ln_b, node_feat, I32(p.ids[l - 1]),
+        hipLaunchKernelGGL(k_tgat_post, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, s, F32(p.fc), h_lower, lmap, ct, Lw.ln_w, Lw.ln_b, node_feat, I32(p.ids[l - 1]),
                            n, p.Dq, p.Fn, F32(p.merge_in), nl);
         DYGNN_LAUNCH_CHECK();
         if (int rc = gemm_nt<true>(F32(p.merge_in), Lw.fc1_w, Lw.fc1_b, F32(p.hid), n, p.Fn, p.Dq + p.Fn, p.Fn, s, nl)) return rc;
