@@ -506,7 +506,7 @@ def bench_lastfm(dev, steps: int = 16, warmup: int = 8, F: int = 8, cpu_budget_s
 
 
 def bench_tgat(dev, steps: int = 64, warmup: int = 3, fuse_steps: int = 32, edges: int = 672447, cpu_budget_s: float = 20.0,
-               cpu_max_steps: int = 30, one_step_calls: int = 20) -> dict:
+               cpu_max_steps: int = 30, one_step_calls: int = 20, uniform_steps: int = 12) -> dict:
     """BASELINE config 3: TGAT link-prediction forward, Reddit-shaped synthetic graph (10,000 + 984 nodes, 672,447 edges), k = 20,
     2 layers, batch 200: pos call + neg call + MergeLayer+sigmoid per step.  Rows do not depend on the batch they are in (fixed k,
     no batch-dependent padding), so F steps are one call on F*200 edges; the one-step-per-call rate is reported beside it."""
@@ -552,7 +552,7 @@ def bench_tgat(dev, steps: int = 64, warmup: int = 3, fuse_steps: int = 32, edge
     total_entries, computed_entries = model.last_level_entries()          # of the last call (F steps, positive and negative together)
     # one step per call (the reference caller's shape): the first `one_step_calls` steps of the last fused call
     s, d, n, t = batches[(warmup + steps // F - 1) % len(batches)]
-    one = [(s[j * B:(j + 1) * B], d[j * B:(j + 1) * B], n[j * B:(j + 1) * B], t[j * B:(j + 1) * B]) for j in range(min(F, one_step_calls))]
+    one = [(s[j * B:(j + 1) * B], d[j * B:(j + 1) * B], n[j * B:(j + 1) * B], t[j * B:(j + 1) * B]) for j in range(max(1, min(F, one_step_calls)))]
     call(*one[0])
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
@@ -575,12 +575,14 @@ def bench_tgat(dev, steps: int = 64, warmup: int = 3, fuse_steps: int = 32, edge
     # the reference's best TGAT configuration on Reddit samples `uniform` (utils/load_configs.py:83-84): the draws are the sampler's numpy
     # RandomState stream, replayed on the host (one library call per level: dygnn_mt19937_choice_rows_host), two calls per step like the
     # reference (evaluate_models_utils.py:126-136).  Parity of this path: the reference's fixtures (tests/golden/tgat_rand_*, sampling_*).
+    if uniform_steps <= 0:           # profiling runs (tools/bench_tgat.py --plain): the fused `recent` calls only
+        return out
     usampler = get_neighbor_sampler(data, "uniform", seed=3, device=dev)
     model.set_neighbor_sampler(usampler)
     hs_, hd_, hn_, ht_ = host[0]
     ustep = lambda j: (merge.link_probabilities(*model.compute_src_dst_node_temporal_embeddings(hs_[j * B:(j + 1) * B], hd_[j * B:(j + 1) * B], ht_[j * B:(j + 1) * B], num_neighbors=K)),
                        merge.link_probabilities(*model.compute_src_dst_node_temporal_embeddings(hs_[j * B:(j + 1) * B], hn_[j * B:(j + 1) * B], ht_[j * B:(j + 1) * B], num_neighbors=K)))
-    nu = min(12, F)
+    nu = min(uniform_steps, F)
     with torch.no_grad():
         ustep(0)
         torch.cuda.synchronize(dev)

@@ -359,14 +359,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // residual branch of the layer (models/modules.py:196-199) rebuilds [h | cos(b)] from the feature row and ct = cos(b).
 __global__ void k_tgat_const_q(const float* __restrict__ Wq, const float* __restrict__ tw, const float* __restrict__ tb, int Dq, int Fn, int Ft,
                                float* __restrict__ cq, float* __restrict__ ct) {
-    extern __shared__ float c_lds[];
-    for (int f = threadIdx.x; f < Ft; f += blockDim.x) { const float v = cosf(fmaf(0.0f, tw[f], tb[f])); c_lds[f] = v; ct[f] = v; }
-    __syncthreads();
-    for (int j = threadIdx.x; j < Dq; j += blockDim.x) {
-        float a = 0.f;
-        for (int f = 0; f < Ft; ++f) a = fmaf(Wq[(size_t)j * Dq + Fn + f], c_lds[f], a);
-        cq[j] = a;
-    }
+    // one wave per output row (4 per workgroup): lanes stride over the Ft time columns (coalesced), partial sums meet by shuffles in a fixed order
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0) for (int f = threadIdx.x; f < Ft; f += blockDim.x) ct[f] = cosf(fmaf(0.0f, tw[f], tb[f]));
+    if (j >= Dq) return;
+    float a = 0.f;
+    for (int f = lane; f < Ft; f += 64) a = fmaf(Wq[(size_t)j * Dq + Fn + f], cosf(fmaf(0.0f, tw[f], tb[f])), a);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) cq[j] = a;
 }
 
 // y = LayerNorm(fc_out + residual) (models/modules.py:196-199), written into the first Dq columns of the MergeLayer input
@@ -439,7 +440,10 @@ __global__ void k_dedup_insert(const int32_t* __restrict__ ids, const double* __
     const double t = times[i];
     uint32_t h = dedup_hash(id, t) & cap_mask;
     for (;;) {
-        const int32_t prev = atomicCAS(&slots[h], -1, (int32_t)i);
+        // look before claiming: a level repeats its popular (node, time) entries hundreds of times, and a compare-and-swap per duplicate on the
+        // representative's slot serialises them (~8 ns each); a slot never changes once claimed, so a plain read of a claimed slot is final
+        int32_t prev = __atomic_load_n(&slots[h], __ATOMIC_RELAXED);
+        if (prev == -1) prev = atomicCAS(&slots[h], -1, (int32_t)i);
         if (prev == -1) { canon[i] = (int32_t)i; return; }
         if (ids[prev] == id && __double_as_longlong(times[prev]) == __double_as_longlong(t)) { canon[i] = prev; return; }
         h = (h + 1) & cap_mask;
@@ -678,7 +682,7 @@ static int tgat_forward_impl(const dygnn_tgat_config* cfg, const dygnn_tgat_weig
             if (int rc = chain::launch_pre(s, pa)) return rc;
         } else {
         // q = W_q[:, :Fn] h + cq (see k_tgat_const_q): the product gathers the feature rows itself
-        hipLaunchKernelGGL(k_tgat_const_q, dim3(1), dim3(256), (size_t)p.Ft * sizeof(float), s, Lw.query_w, w->time_w, w->time_b, p.Dq, p.Fn, p.Ft, cq, ct);
+        hipLaunchKernelGGL(k_tgat_const_q, dim3((unsigned)ceil_div(p.Dq, 4)), dim3(256), 0, s, Lw.query_w, w->time_w, w->time_b, p.Dq, p.Fn, p.Ft, cq, ct);
         DYGNN_LAUNCH_CHECK();
         if (n >= 48) {
             if (int rc = train::mm(s, h_lower ? h_lower : node_feat, p.Fn, false, Lw.query_w, p.Dq, true, F32(p.q), p.Dq, (int)n, p.Dq, p.Fn, cq, 1.f, 0.f, 1, 1, 0, 0, 0, 0,
