@@ -505,7 +505,7 @@ def bench_lastfm(dev, steps: int = 16, warmup: int = 8, F: int = 8, cpu_budget_s
     return out
 
 
-def bench_tgat(dev, steps: int = 64, warmup: int = 3, fuse_steps: int = 32, edges: int = 672447, cpu_budget_s: float = 20.0,
+def bench_tgat(dev, steps: int = 192, warmup: int = 3, fuse_steps: int = 32, edges: int = 672447, cpu_budget_s: float = 20.0,
                cpu_max_steps: int = 30, one_step_calls: int = 20, uniform_steps: int = 12) -> dict:
     """BASELINE config 3: TGAT link-prediction forward, Reddit-shaped synthetic graph (10,000 + 984 nodes, 672,447 edges), k = 20,
     2 layers, batch 200: pos call + neg call + MergeLayer+sigmoid per step.  Rows do not depend on the batch they are in (fixed k,

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--steps", type=int, default=64); ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--steps", type=int, default=192); ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--edges", type=int, default=672447); ap.add_argument("--cpu-seconds", type=float, default=20.0)
 ap.add_argument("--fuse-steps", type=int, default=32)
 ap.add_argument("--plain", action="store_true", help="the fused `recent` calls only (profiling): no one-step calls beyond the first, no `uniform` leg, no CPU leg")
