@@ -8,18 +8,23 @@ synthetic workload of SURVEY.md §8(d): L=64, P=2, batch 200, 2 layers, 2 heads,
            bench.py --gpus N --steps K --warmup W
 
 One step = one 200-edge batch: hot-path call on (src,dst,t) + hot-path call on (src,neg_dst,t) +
-sigmoid(MergeLayer) on both + the per-step metric (AUC numerator) reduced over RCCL when N>1.
+sigmoid(MergeLayer) on both + the per-step ROC AUC on the device; the per-rank metric sums are all-reduced over RCCL
+ONCE, after the timed region (`metric_allreduce` in the line), when N>1.
 Inputs (graph, feature tables, weights, every batch's id/time arrays) are resident in HBM before the
 timed region.  N>1: one process per GPU, graph/tables/weights replicated, whole batches dealt
 round-robin (dyglib_amd.distributed.shard_batch_indices: rank r takes batches r, r+N, ...: weak
-scaling, K steps per rank), no data-path collective.  Rank 0 prints ONE JSON line.
+scaling, K steps per rank), no data-path collective; the synthetic graph is generated once per node (local rank 0 ->
+/dev/shm -> the other ranks).  At N>1 the line also carries `secondary.lastfm`: BASELINE config 4's workload (L=512,
+P=8) sharded over the N ranks the same way.  Rank 0 prints ONE JSON line.
+DYGNN_BENCH_FORCE_DIST=1 sets the process group up at world size 1 too (RCCL rehearsal on a one-GPU box).
 
 Besides the contract fields the line carries (rank 0, N = 1):
   parity     the GPU outputs of the timed steps the CPU leg replays, against the oracle: full-size config-1 parity
              observed by whoever runs this file; the process exits non-zero above the 1e-4 bar of BASELINE.json;
-  stages     neighbour-lookup rate (bytes by SURVEY §8d's formula), device metrics, and `per_call`: the drop-in rate of
+  stages     neighbour-lookup rate (bytes by SURVEY §8d's formula), device metrics, `per_call`: the drop-in rate of
              evaluate_models_utils.py:49-152 — one 200-edge step per launch, numpy inputs, through
-             dyglib_amd.evaluate_model_link_prediction(fuse_batches=1);
+             dyglib_amd.evaluate_model_link_prediction(fuse_batches=1) — and `full_span`: all 237 batches of the
+             evaluation span through the same loop, mean AP / AUC, per-batch AP / AUC of six batches against the oracle;
   secondary  short runs of BASELINE configs 3 (TGAT), 4 (LastFM-shaped DyGFormer, one GPU's share), 5 (TGN) and of the
              training step, each with value, ms/step, roofline and a warmed CPU sample.
 """
