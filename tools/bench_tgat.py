@@ -11,5 +11,5 @@ ap.add_argument("--edges", type=int, default=672447); ap.add_argument("--cpu-sec
 ap.add_argument("--fuse-steps", type=int, default=32)
 ap.add_argument("--plain", action="store_true", help="the fused `recent` calls only (profiling): no one-step calls beyond the first, no `uniform` leg, no CPU leg")
 a = ap.parse_args()
-kw = dict(one_step_calls=1, uniform_steps=0, cpu_budget_s=0.0) if a.plain else dict(cpu_budget_s=a.cpu_seconds)
+kw = dict(one_step_calls=1, uniform_steps=0, cpu_budget_s=0.0, larger_calls=()) if a.plain else dict(cpu_budget_s=a.cpu_seconds)
 print(json.dumps(bench.bench_tgat("cuda:0", steps=a.steps, warmup=a.warmup, fuse_steps=a.fuse_steps, edges=a.edges, **kw)))
