@@ -350,11 +350,13 @@ __device__ __forceinline__ void layernorm(f4 (&xn)[kNT], const f4 (&x)[kNT], con
     }
 }
 
-// acc[7] += W(7 tiles of one head's q, k or v) . xn : 13 stream steps of 7 fragments [k-chunk][tile], each multiplied
-// as sub-groups of 4 and 3 tiles whose fragments are read one sub-group ahead (8 fragments live instead of 14)
-__device__ __forceinline__ void qkv_group(f4 (&acc)[7], const f4 (&xn)[kNT], const float xk0, const float xk1, WStream& ws, const float* ringl, bool active) {
+// acc[NT] += W(NT tiles of one head's q, k or v) . xn : 13 stream steps of NT fragments [k-chunk][tile], each multiplied
+// as sub-groups of 4 and NT - 4 tiles whose fragments are read one sub-group ahead (8 fragments live instead of 14)
+template <int NT>
+__device__ __forceinline__ void qkv_group(f4 (&acc)[NT], const f4 (&xn)[kNT], const float xk0, const float xk1, WStream& ws, const float* ringl, bool active) {
+    constexpr int N2 = NT - 4;
     f4 fs[2][4];
-    ws.fit(7);
+    ws.fit(NT);
     if (active) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) fs[0][u] = lds4(ringl + (ws.pos + u) * kFrag);
@@ -363,21 +365,21 @@ __device__ __forceinline__ void qkv_group(f4 (&acc)[7], const f4 (&xn)[kNT], con
     for (int kc = 0; kc < kKC; ++kc) {
         if (active) {
 #pragma unroll
-            for (int u = 0; u < 3; ++u) fs[1][u] = lds4(ringl + (ws.pos + 4 + u) * kFrag);
+            for (int u = 0; u < N2; ++u) fs[1][u] = lds4(ringl + (ws.pos + 4 + u) * kFrag);
             __builtin_amdgcn_sched_barrier(0);
             if (F3_KSKIP && kc == kKC - 1) mma_group2<4>(&acc[0], fs[0], xk0, xk1); else mma_group<4>(&acc[0], fs[0], xn[kc]);
             __builtin_amdgcn_sched_barrier(0);
             if (kc + 1 < kKC) {
-                const int p1 = ws.next_pos(7, 7);
+                const int p1 = ws.next_pos(NT, NT);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) fs[0][u] = lds4(ringl + (p1 + u) * kFrag);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (F3_KSKIP && kc == kKC - 1) mma_group2<3>(&acc[4], fs[1], xk0, xk1); else mma_group<3>(&acc[4], fs[1], xn[kc]);
+            if (F3_KSKIP && kc == kKC - 1) mma_group2<N2>(&acc[4], fs[1], xk0, xk1); else mma_group<N2>(&acc[4], fs[1], xn[kc]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        ws.advance(7);
-        if (kc + 1 < kKC) ws.fit(7);
+        ws.advance(NT);
+        if (kc + 1 < kKC) ws.fit(NT);
     }
 }
 
@@ -976,12 +978,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_dygformer_fused3(c
             // ================= Q, K, V of head h =================
             f4 qa[7];
             {
-                ws.fit(1);               // bias fragment: rows 100h .. 100h+99 of the q bias, zero padded
+                ws.fit(1);               // bias fragment: rows 100h .. 100h+99 of the q bias; elements 100 .. 107: the k and v bias of rows 96 .. 99
                 const float* bq = lds + kLdsRing + ws.pos * kFrag + 4 * g;
 #pragma unroll
                 for (int j = 0; j < 7; ++j) qa[j] = lds4(bq + 16 * j);
                 ws.advance(1);
                 qkv_group(qa, xn, xk0, xk1, ws, ringl, active);
+                // Tile 6 is the COMBINED tile of the head (FragDesc kmode 8): lane group 0 holds rows 96 .. 99 of Q^T, group 1 those of K^T, group 2
+                // those of V^T (the K and V parts below run 6 tiles instead of 7: 9.5 % of the layer's QKV MFMAs).  Every wave passed a stream
+                // barrier since its last read of the previous head's K / V (the out-projection and this group lie in between): their rows
+                // can be written.
+                if (active && (g == 1 || g == 2)) *reinterpret_cast<f4*>((g == 2 ? Vb : Kb) + (tokbase + 16 * tt + c) * kKV + 96) = qa[6];
+                if constexpr (TR) {
+                    if (tokv && (g == 1 || g == 2)) *reinterpret_cast<f4*>(a.tr.layer[l].qkv + trow * (3 * kD) + g * kD + kHD * h + 96) = qa[6];
+                }
+                if (g != 0) qa[6] = zero4();          // rows 100 .. 111 of Q^T do not exist
                 if constexpr (TR) {
                     if (tokv) {
                         float* qp = a.tr.layer[l].qkv + trow * (3 * kD) + kHD * h + 4 * g;
@@ -995,27 +1006,23 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_dygformer_fused3(c
             }
 #pragma unroll 1
             for (int kv = 0; kv < 2; ++kv) {
-                f4 acc[7];
+                f4 acc[6];               // rows 0 .. 95 of K^T / V^T (rows 96 .. 99 came out of the combined tile above)
                 ws.fit(1);
                 const float* bk = lds + kLdsRing + ws.pos * kFrag + 4 * g;
 #pragma unroll
-                for (int j = 0; j < 7; ++j) acc[j] = lds4(bk + 16 * j);
+                for (int j = 0; j < 6; ++j) acc[j] = lds4(bk + 16 * j);
                 ws.advance(1);
                 qkv_group(acc, xn, xk0, xk1, ws, ringl, active);
-                // every wave passed a stream barrier since its last read of the previous head's K/V (the out-projection
-                // and the Q group lie in between), so the rows can be overwritten
                 if (active) {
                     float* row = (kv ? Vb : Kb) + (tokbase + 16 * tt + c) * kKV + 4 * g;
 #pragma unroll
-                    for (int j = 0; j < 7; ++j)
-                        if (j < 6 || g == 0) *reinterpret_cast<f4*>(row + 16 * j) = acc[j];     // cols >= 100 belong to the next row
+                    for (int j = 0; j < 6; ++j) *reinterpret_cast<f4*>(row + 16 * j) = acc[j];
                 }
                 if constexpr (TR) {
                     if (tokv) {
                         float* kp = a.tr.layer[l].qkv + trow * (3 * kD) + (kv + 1) * kD + kHD * h + 4 * g;
 #pragma unroll
-                        for (int j = 0; j < 7; ++j)
-                            if (j < 6 || g == 0) *reinterpret_cast<f4*>(kp + 16 * j) = acc[j];
+                        for (int j = 0; j < 6; ++j) *reinterpret_cast<f4*>(kp + 16 * j) = acc[j];
                     }
                 }
             }
@@ -1849,24 +1856,34 @@ struct FragDesc {
     int kmode;            // 1: last chunk of a K = 200 product, 8 real k in two MFMAs: t < 2: col = c0 + {0,4,1,5}[g] + 2t, t >= 2: zero (mma_group2)
                           // 2: last chunk of a head-dim (100) contraction, 4 real k in one MFMA: t = 0: col = c0 + g, t >= 1: zero (mma_group1)
                           // +4: transposed source, element (row, col) = src[col * ld + row] (the backward stream: W^T fragments of the same tensors)
+                          // +8: the COMBINED last head-dim tile of a head's q | k | v (src = in_proj base, r0 = 100 h + 96): rows 4 G .. 4 G + 3 of the tile
+                          //     are rows r0 .. r0 + 3 of row block G (q, k, v at G = 0, 1, 2: row = r0 + 200 G + (c & 3)), G = 3 is padding.  The three
+                          //     parts' tiles 6 hold 4 real rows each (head dim 100 = 6 tiles + 4): one MFMA tile carries all twelve.
+                          //     Vector fragment (+8): elements 100 .. 107 = src[c0 + 200 + 96 ..], src[c0 + 400 + 96 ..] (the k and v bias of those rows)
 };
+__device__ __forceinline__ float frag_element(const FragDesc& d, int e) {       // e = 4 * lane + t of the fragment
+    if (d.src == nullptr) return 0.f;
+    const int t = e & 3, lane = (e >> 2) & 63;
+    const int c = lane & 15, g = lane >> 4;
+    if (d.ld < 0) {
+        if (e < d.rmax) return d.src[d.c0 + e];
+        if ((d.kmode & 8) && e >= 100 && e < 108) return d.src[d.c0 + kD * ((e - 100) / 4 + 1) + 96 + ((e - 100) & 3)];
+        return 0.f;
+    }
+    int row = d.r0 + c;
+    bool rok = row >= 0 && row < d.rmax;
+    if (d.kmode & 8) { row = d.r0 + kD * (c >> 2) + (c & 3); rok = (c >> 2) < 3; }
+    int col = d.c0 + 4 * g + t;
+    if ((d.kmode & 3) == 1) col = t < 2 ? d.c0 + (g & 1) * 4 + (g >> 1) + 2 * t : d.cmax;
+    if ((d.kmode & 3) == 2) col = t == 0 ? d.c0 + g : d.cmax;
+    if (!rok || col >= d.cmax) return 0.f;
+    return (d.kmode & 4) ? d.src[(size_t)col * d.ld + row] : d.src[(size_t)row * d.ld + col];
+}
 
 __global__ void k_pack_stream(const FragDesc* __restrict__ desc, int64_t nfrag, float* __restrict__ dst) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nfrag * kFrag) return;
-    const int t = idx & 3, lane = (idx >> 2) & 63;
-    const FragDesc d = desc[idx >> 8];
-    const int c = lane & 15, g = lane >> 4;
-    const int row = d.r0 + c;
-    int col = d.c0 + 4 * g + t;
-    if ((d.kmode & 3) == 1) col = t < 2 ? d.c0 + (g & 1) * 4 + (g >> 1) + 2 * t : d.cmax;
-    if ((d.kmode & 3) == 2) col = t == 0 ? d.c0 + g : d.cmax;
-    float v = 0.f;
-    if (d.src != nullptr) {
-        if (d.ld < 0) { const int e = (int)(idx & 255); if (e < d.rmax) v = d.src[d.c0 + e]; }
-        else if (row >= 0 && row < d.rmax && col < d.cmax) v = (d.kmode & 4) ? d.src[(size_t)col * d.ld + row] : d.src[(size_t)row * d.ld + col];
-    }
-    dst[idx] = v;
+    dst[idx] = frag_element(desc[idx >> 8], (int)(idx & 255));
 }
 
 // every fragment stream of the packed buffer in ONE launch (the in-place refresh after an optimizer step): the descriptor table is one
@@ -1878,19 +1895,7 @@ __global__ void k_pack_ranges(const FragDesc* __restrict__ desc, const PackRange
     if (f >= r.start[r.n]) return;
     int q = 0;
     while (q + 1 < r.n && f >= r.start[q + 1]) ++q;
-    const int t = idx & 3, lane = (idx >> 2) & 63;
-    const FragDesc d = desc[f];
-    const int c = lane & 15, g = lane >> 4;
-    const int row = d.r0 + c;
-    int col = d.c0 + 4 * g + t;
-    if ((d.kmode & 3) == 1) col = t < 2 ? d.c0 + (g & 1) * 4 + (g >> 1) + 2 * t : d.cmax;
-    if ((d.kmode & 3) == 2) col = t == 0 ? d.c0 + g : d.cmax;
-    float v = 0.f;
-    if (d.src != nullptr) {
-        if (d.ld < 0) { const int e = (int)(idx & 255); if (e < d.rmax) v = d.src[d.c0 + e]; }
-        else if (row >= 0 && row < d.rmax && col < d.cmax) v = (d.kmode & 4) ? d.src[(size_t)col * d.ld + row] : d.src[(size_t)row * d.ld + col];
-    }
-    r.dst[q][(f - r.start[q]) * kFrag + (idx & 255)] = v;
+    r.dst[q][(f - r.start[q]) * kFrag + (idx & 255)] = frag_element(desc[f], (int)(idx & 255));
 }
 // the four projection biases in model-dim order [208]
 __global__ void k_pack_bias4(const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ b3, float* __restrict__ dst) {
@@ -1927,13 +1932,18 @@ static void build_stream(const Dims& d, const dygnn_dygformer_weights* w, Stream
         sb.put_vec(L.norm0_bias, 0, kD);
         for (int h = 0; h < 2; ++h) {
             for (int part = 0; part < 3; ++part) {           // q, k, v row blocks of in_proj
+                // q: 7 tiles, the seventh = the COMBINED tile (rows 96 .. 99 of q, k and v: FragDesc kmode 8); k, v: tiles 0 .. 5
+                const int nt = part == 0 ? 7 : 6;
                 sb.fit(1);
-                sb.put_vec(L.in_proj_bias, part * kD + kHD * h, kHD);      // head rows of the bias, zero beyond 100
-                sb.fit(7);
+                if (part == 0) sb.frags.push_back(FragDesc{L.in_proj_bias, -1, 0, kHD, kHD * h, 0, 8}), sb.pos = (sb.pos + 1) % kRing;
+                else sb.put_vec(L.in_proj_bias, part * kD + kHD * h, kHD);      // head rows of the bias (elements 0 .. 95 are read)
+                sb.fit(nt);
                 for (int kc = 0; kc < kKC; ++kc) {
-                    for (int j = 0; j < 7; ++j)
-                        sb.put(L.in_proj_weight + (size_t)part * kD * kD, kD, kHD * h + 16 * j, kHD * (h + 1), 16 * kc, kD, F3_KSKIP && kc == kKC - 1);
-                    if (kc + 1 < kKC) sb.fit(7);
+                    const int ks = (F3_KSKIP && kc == kKC - 1) ? 1 : 0;
+                    for (int j = 0; j < 6; ++j)
+                        sb.put(L.in_proj_weight ? L.in_proj_weight + (size_t)part * kD * kD : nullptr, kD, kHD * h + 16 * j, kHD * (h + 1), 16 * kc, kD, ks);
+                    if (part == 0) sb.put(L.in_proj_weight, kD, kHD * h + 96, 3 * kD, 16 * kc, kD, ks | 8);
+                    if (kc + 1 < kKC) sb.fit(nt);
                 }
             }
             sb.fit(13);
