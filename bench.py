@@ -760,12 +760,15 @@ def bench_tgn(dev, steps: int = 100, warmup: int = 60, cpu_budget_s: float = 10.
     return out
 
 
-def bench_train(dev, steps: int = 20, warmup: int = 8, separate_calls: bool = False, cpu_budget_s: float = 12.0, cpu_max_steps: int = 30) -> dict:
+def bench_train(dev, steps: int = 20, warmup: int = 8, separate_calls: bool = False, cpu_budget_s: float = 12.0, cpu_max_steps: int = 30,
+                shape: str = "wikipedia") -> dict:
     """Training-step throughput of the DyGFormer path: train_link_prediction.py:229-257 in miniature on the
-    Wikipedia-shaped workload — positive + negative call in train mode (dropout 0.1), MergeLayer, BCE, backward, Adam step."""
+    Wikipedia-shaped workload — positive + negative call in train mode (dropout 0.1), MergeLayer, BCE, backward, Adam step.
+    shape="lastfm": the same step at BASELINE config 4's shape (L=512, P=8: 128 tokens per pair, the <8> kernels), GPU timing only."""
     from dyglib_amd import DyGFormer, MergeLayer, get_neighbor_sampler
-    B, L, P = 200, 64, 2
-    data, nf, ef = syn.make_bipartite_graph(8227, 1000, 157474, seed=0)
+    wl = WORKLOADS[shape]
+    B, L, P = wl["batch"], wl["L"], wl["P"]
+    data, nf, ef = syn.make_bipartite_graph(wl["users"], wl["items"], wl["edges"], seed=0, edge_feat_kind=wl["edge_feat_kind"])
     params = syn.make_dygformer_params(0, patch_size=P)
     mparams = syn.make_merge_layer_params(1000)
     sampler = get_neighbor_sampler(data, "recent", seed=1, device=dev)
@@ -824,6 +827,11 @@ def bench_train(dev, steps: int = 20, warmup: int = 8, separate_calls: bool = Fa
     gpu_ms = e0.elapsed_time(e1) / steps          # main-stream span: equals the wall time when the GPU, not the host, sets the pace
     # forward + backward = 3x the forward's algorithmic flops (each product has two gradient products): 3 * 2B pairs * 137.2 MFLOP
     flop = 3 * 2 * B * flops_per_pair(L, L, P)
+    if shape != "wikipedia":          # the long-window shape: the step's rate and fraction only (its CPU autograd step takes tens of seconds)
+        return {"value": round(B / sec, 1), "unit": "edges/s", "ms_per_step": round(sec * 1e3, 4), "gpu_stream_ms_per_step": round(gpu_ms, 4), "steps": steps,
+                "config": {"workload": f"DyGFormer training step, synthetic {shape}-shaped graph, L={L}, P={P}, batch={B}, dropout 0.1, Adam; pos+neg as one pass"},
+                "roofline": {"bound": "mfma", "achieved": round(flop / sec / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(flop / sec / (PEAK_F32_MFMA_TFLOPS * 1e12), 4), "flop_per_step": flop}, "final_loss": round(float(loss.detach()), 4)}
     out = {"metric": "edges/sec (link-prediction TRAIN step: fwd pos+neg, bwd, Adam) DyGFormer Wikipedia-shaped", "value": round(B / sec, 1),
            "unit": "edges/s", "ms_per_step": round(sec * 1e3, 4), "gpu_stream_ms_per_step": round(gpu_ms, 4), "steps": steps, "warmup": warmup, "priming": "0.5 s of untimed steps (clock ramp)", "dropout": 0.1, "final_loss": round(float(loss.detach()), 4),
            "config": {"workload": "DyGFormer training step, synthetic wikipedia-shaped graph, L=64, P=2, batch=200, dropout 0.1, Adam",
@@ -845,6 +853,12 @@ def bench_train(dev, steps: int = 20, warmup: int = 8, separate_calls: bool = Fa
         separate_calls = False
         out["two_calls_per_step"] = {"value": round(B / sec2, 1), "unit": "edges/s", "ms_per_step": round(sec2 * 1e3, 4), "steps": 10,
                                      "what": "the same step with the reference's two separate forward calls (every kernel on half the grid)"}
+        del model, opt
+        torch.cuda.empty_cache()
+        try:      # the L=512 / P=8 training shape (k_dygformer_fused3<8, true>, k_attn_bwd<8>, k_ffn_bwd<8>)
+            out["lastfm_shape"] = bench_train(dev, steps=6, warmup=3, cpu_budget_s=0.0, shape="lastfm")
+        except Exception as e:
+            out["lastfm_shape"] = {"error": f"{type(e).__name__}: {e}"}
     if cpu_budget_s > 0:
         from oracle import dygformer_oracle as orc
         torch.set_num_threads(cpu_threads())
