@@ -143,6 +143,42 @@ def test_wikipedia_scale_batch_against_oracle():
             close(gd.cpu().numpy(), od.numpy(), f"impl {impl} dst")
 
 
+@pytest.mark.parametrize("L,P,paired", [(256, 8, False), (256, 8, True), (256, 4, False)])
+def test_long_windows_with_the_hash_table_counts_against_oracle(L, P, paired):
+    """Windows of >= 512 positions per pair count their co-occurrences through the LDS hash table of the fused kernel (round 3).  The reference
+    fixtures reach it with one pair per workgroup only (L = 512 / P = 8); here: L = 256 / P = 8 = 64 tokens per pair = TWO pairs per workgroup, each
+    with its own table (also as the positive / negative pair of one edge), and L = 256 / P = 4 = 128 tokens (one pair) — hub items with many repeated
+    neighbours (counts far above 1), empty histories, duplicate timestamps.  No reference fixture holds these shapes: the oracle is the bar."""
+    from dyglib_amd import DyGFormer, get_neighbor_sampler, count_nodes_appearances
+    data, nf, ef = syn.make_bipartite_graph(40, 6, 9000, seed=23, duplicate_time_every=5)
+    nf[1:] = np.random.RandomState(2).standard_normal(nf[1:].shape).astype(np.float32) * 0.3
+    params = syn.make_dygformer_params(9, patch_size=P)
+    sampler = get_neighbor_sampler(data, "recent", seed=1, device="cuda:0")
+    model = DyGFormer(nf, ef, sampler, 100, 50, patch_size=P, num_layers=2, num_heads=2, dropout=0.1, max_input_sequence_length=L, device="cuda:0")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    model = model.to("cuda:0").eval()
+    adj = orc.OracleAdjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    idx = np.concatenate([np.arange(4), np.arange(data.num_interactions - 44, data.num_interactions)])       # 48 pairs, incl. first interactions
+    src, dst, t = data.src_node_ids[idx], data.dst_node_ids[idx], data.node_interact_times[idx]
+    neg = syn.random_negative_dst(np.random.RandomState(4), np.unique(data.dst_node_ids), len(idx))
+    with torch.no_grad():
+        os_, od = orc.dygformer_forward(params, nf, ef, adj, src, dst, t, P, L)
+        ons, ond = orc.dygformer_forward(params, nf, ef, adj, src, neg, t, P, L)
+        if paired:       # [positives ; negatives] as one launch, pair i and pair i + B in one workgroup
+            s2, d2 = model.compute_src_dst_node_temporal_embeddings_many(np.stack([src, src]), np.stack([dst, neg]), np.stack([t, t]), pos_neg_halves=True)
+            gs, gd, gns, gnd = s2[0], d2[0], s2[1], d2[1]
+        else:
+            gs, gd = model.compute_src_dst_node_temporal_embeddings(src, dst, t)
+            gns, gnd = model.compute_src_dst_node_temporal_embeddings(src, neg, t)
+    for got, want, tag in ((gs, os_, "src"), (gd, od, "dst"), (gns, ons, "neg src"), (gnd, ond, "neg dst")):
+        close(got.cpu().numpy(), want.numpy(), f"L={L} P={P} paired={paired} {tag} emb", label=f"long windows, hash-table counts (L={L}, P={P})")
+    # the windows really are long and repetitive: some count exceeds 50
+    ids_s, _, _ = sampler.padded_windows(src, t, P, L)
+    ids_d, _, _ = sampler.padded_windows(dst, t, P, L)
+    cs, cd = count_nodes_appearances(ids_s, ids_d, device="cuda:0")
+    assert ids_s.shape[1] + ids_d.shape[1] >= 256 and float(cs.max()) > 50
+
+
 @pytest.mark.parametrize("name", ["bip_p2_l64", "hub_p4_l48", "gen_p1_l32", "bip_p8_l512"])
 def test_positive_and_negative_call_in_one_workgroup_match_separate_calls(name):
     """SURVEY §8f-4 for DyGFormer: [positive calls ; negative calls] with pos_neg_halves=True puts both pairs of an edge in one workgroup
