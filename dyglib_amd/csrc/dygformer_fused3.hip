@@ -535,7 +535,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_dygformer_fused3(c
     }
     const bool donor = NP == 2 && paired && pi == 0 && 16 * (tt + 1) <= Ts;     // first-pair tiles a shared tile may copy from (checked by the taker)
 
-    // ---- weights start moving at once: the first four stages of the layer stream into the ring, the first slab of
+    // ---- weights start moving at once: the first four stages of the layer stream into the ring, the first two halves of
     // projection fragments into the K/V region behind the window arrays (all of it lands during the window phase)
     WStream ws;
     if (!a.slab_in_ring) ws.open(a.stream, kLdsRing, lane, wave, a.nstages, NW);
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_dygformer_fused3(c
             c0[p] = cs; c1[p] = cdn;
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of slab 0 and of the first ring stages has landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the first two projection halves and of the first ring stages has landed
     __syncthreads();
 
     TACC(T_WIN);
@@ -653,11 +653,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_dygformer_fused3(c
     for (int i = 0; i < kNT; ++i) x[i] = ldg4(a.bias_x + 16 * i + 4 * g);
 
     // ---- patch projection (DyGFormer.py:148-157): channel ch writes model rows 50ch..50ch+49 = tiles (50ch)/16 .. +3.
-    // One step = one 16-wide k-chunk x 4 tiles; the fragments of up to slab_chunks steps sit in an LDS slab (loaded by
-    // LDS-DMA, all waves use the same ones), so inside a slab nothing synchronises and the B operand — gathered straight
-    // from the feature tables, (pp, f) = (patch position, feature) of this lane's k advanced incrementally — runs
-    // eight chunks ahead.  Channel order node, time, edge, cooc: the edge gathers are issued before the time channel
-    // computes its cosines, the node gathers before the co-occurrence counts.
+    // One step = one 16-wide k-chunk x 4 tiles; the fragments of `slab_chunks` steps sit in an LDS half (loaded by LDS-DMA one half
+    // ahead, all waves use the same ones), so inside a half nothing synchronises and the B operand — gathered straight from the feature
+    // tables, (pp, f) = (patch position, feature) of this lane's k advanced incrementally — runs four chunks ahead.  Channel order
+    // node, time, edge, cooc: the edge gathers are issued before the time channel computes its cosines.
     {
         const int tok = 16 * tt + c;
         const bool tv = tok < T;
