@@ -84,7 +84,7 @@ def _build(name, dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(gc.EVAL_CASES))
-@pytest.mark.parametrize("fuse", [1, 5])
+@pytest.mark.parametrize("fuse", [1, 5, None])
 def test_evaluation_loop_matches_reference(name, fuse):
     import torch
     from dyglib_amd import Data, evaluate_model_link_prediction, get_idx_data_loader
@@ -97,7 +97,8 @@ def test_evaluation_loop_matches_reference(name, fuse):
     loader = get_idx_data_loader(list(range(last - first)), r["batch"], shuffle=False)
     losses, metrics = evaluate_model_link_prediction(model_name=r["model"], model=model, neighbor_sampler=sampler, evaluate_idx_data_loader=loader,
                                                      evaluate_neg_edge_sampler=_neg_sampler(d), evaluate_data=eval_data,
-                                                     loss_func=torch.nn.BCELoss(), num_neighbors=cfg.get("num_neighbors", 20), fuse_batches=fuse)
+                                                     loss_func=torch.nn.BCELoss(), num_neighbors=cfg.get("num_neighbors", 20),
+                                                     **({} if fuse is None else dict(fuse_batches=fuse, tgat_fuse_batches=fuse)))      # None: the defaults (32 / TGAT 128)
     assert len(losses) == len(metrics) == len(g["losses"]) and all(isinstance(x, float) for x in losses)
     assert np.abs(np.array(losses) - g["losses"]).max() <= 1e-5
     assert np.abs(np.array([m["roc_auc"] for m in metrics]) - g["roc_auc"]).max() <= 2e-3
