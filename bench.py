@@ -176,7 +176,7 @@ class DygformerWorkload:
                 f"L={self.L}, P={self.P}, batch={self.B}, 2 layers, 2 heads, C=50; pos+neg calls + MergeLayer+sigmoid per step")
 
 
-def run_dygformer(wk: DygformerWorkload, steps: int, warmup: int, F: int, rank: int, world: int, dist, n_streams: int = 1, keep: int = 0, prime: int = 8) -> dict:
+def run_dygformer(wk: DygformerWorkload, steps: int, warmup: int, F: int, rank: int, world: int, dist, n_streams: int = 1, keep: int = 0, prime: int = 12) -> dict:
     """K timed steps of this rank in launches of F steps (the positive and negative calls of F consecutive steps = 2F
     independently padded groups of B pairs form ONE grid).  Returns throughput, the per-launch duration of the hot-path
     call from HIP events recorded on its stream, and the device outputs of the first `keep` timed steps."""
@@ -897,7 +897,7 @@ def parse_args():
     ap.add_argument("--fuse-steps", type=int, default=32,
                     help="upper bound of the steps per launch: the positive and negative calls of F consecutive steps (2F independently "
                          "padded groups of `batch` pairs) form ONE grid; F = min(this, steps/2) so that at least two launches are timed")
-    ap.add_argument("--prime-launches", type=int, default=8, help="untimed launches of the timed shape before the warm-up steps (clock / cache ramp)")
+    ap.add_argument("--prime-launches", type=int, default=12, help="untimed launches of the timed shape before the warm-up steps (clock / cache ramp)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the headline CPU-baseline sample (0 = skip CPU legs and parity)")
     ap.add_argument("--secondary", default="lastfm,tgat,tgn,train", help="comma list of secondary workloads to run at N=1 ('' or 'none' = skip)")
     ap.add_argument("--full-span-oracle", action="store_true", help="stages.full_span: recompute ALL 237 batches' AP / AUC with the CPU oracle (~1 min)")
