@@ -501,6 +501,7 @@ def full_span_stage(wk: DygformerWorkload, oracle_batches: int = 6, oracle_all: 
 def bench_lastfm(dev, steps: int = 16, warmup: int = 8, F: int = 8, cpu_budget_s: float = 10.0, cpu_max_steps: int = 30) -> dict:
     """BASELINE config 4's shape on one GPU (its 8-GPU form is `--workload lastfm --gpus 8`): L=512, P=8 -> 128 tokens per pair."""
     wk = DygformerWorkload("lastfm", dev)
+    _prime_gpu(dev)               # the leg follows the headline's CPU sample (seconds of host-only work): clock ramp
     res = run_dygformer(wk, steps, warmup, F, 0, 1, None, keep=min(steps, cpu_max_steps) if cpu_budget_s > 0 else 0)
     out = {"metric": "edges/sec (link-prediction fwd) DyGFormer LastFM-shaped (config 4), 1 GPU", "value": round(res["value"], 1), "unit": "edges/s",
            "steps": steps, "warmup": warmup, "ms_per_step": round(res["elapsed"] / steps * 1e3, 4), "steps_per_launch": res["steps_per_launch"],
