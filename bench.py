@@ -108,18 +108,18 @@ def build_graph_once_per_node(name: str, share=None):
     dist, local_rank, tag = share
     d = os.path.join("/dev/shm", f"dygnn_bench_{tag}_{name}")
     fields = ("src_node_ids", "dst_node_ids", "node_interact_times", "edge_ids", "labels")
-    out, err = None, None
+    out = None
     if local_rank == 0:
+        out = gen()
         try:
             shutil.rmtree(d, ignore_errors=True)
             os.makedirs(d)
-            data, nf, ef = out = gen()
+            data, nf, ef = out
             for f in fields:
                 np.save(os.path.join(d, f + ".npy"), getattr(data, f))
             np.save(os.path.join(d, "node_feat.npy"), nf)
             np.save(os.path.join(d, "edge_feat.npy"), ef)
-        except Exception as e:          # the other ranks must not hang in the barrier: they fall back to generating on their own
-            err = e
+        except Exception:               # /dev/shm full or not writable: the other ranks find no files and generate the graph themselves
             shutil.rmtree(d, ignore_errors=True)
     dist.barrier()
     if local_rank != 0:
@@ -131,8 +131,6 @@ def build_graph_once_per_node(name: str, share=None):
     dist.barrier()
     if local_rank == 0:
         shutil.rmtree(d, ignore_errors=True)
-        if err is not None:
-            raise err
     return out
 
 
